@@ -1,0 +1,56 @@
+"""Build libhamer_hip.so for gfx950 with hipcc, in-tree (hamer_yolo_amd/libhamer_hip.so).
+
+hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the repo
+snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libhamer_hip.so")
+SOURCES = ["status.hip", "gemm.hip", "norm.hip", "attention.hip", "patch.hip", "decoder.hip", "mano.hip", "forward.hip"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hamer_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        outp, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"[build] {src} FAILED\n{outp}\n")
+        elif verbose and outp.strip():
+            sys.stderr.write(f"[build] {src}:\n{outp}\n")
+    if failed:
+        raise RuntimeError("hipcc failed building libhamer_hip.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    if verbose:
+        sys.stderr.write(f"[build] wrote {LIB}\n")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

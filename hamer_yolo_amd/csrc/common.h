@@ -1,0 +1,65 @@
+// Shared device helpers for the gfx950 (CDNA4, MI355X) kernels of libhamer_hip.
+// Wavefront = 64 lanes everywhere; MFMA fragment maps follow the 16x16x32 bf16/f16 shape:
+//   A operand: lane l holds A[row l&15][k = 8*(l>>4) + j], j = 0..7
+//   B operand: lane l holds B[k = 8*(l>>4) + j][col l&15]
+//   C/D      : lane l holds D[row 4*(l>>4) + r][col l&15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// Element-type policies: both run on the same MFMA pipe at the same rate.
+struct TBf16 {
+  using elem = __bf16;
+  using vec8 = bf16x8_t;
+  using vec4 = bf16x4_t;
+  static __device__ __forceinline__ f32x4_t mfma(vec8 a, vec8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct TF16 {
+  using elem = _Float16;
+  using vec8 = f16x8_t;
+  using vec4 = f16x4_t;
+  static __device__ __forceinline__ f32x4_t mfma(vec8 a, vec8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4).  The LDS destination
+// is the wave-uniform `lds_base` plus lane*16; the global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU (torch.nn.GELU default; vit.py:77, pose_transformer.py:45)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware, bijective block remap: blocks b and b+8 share an XCD (and its L2) under the
+// round-robin dispatch, so give each XCD a contiguous run of tile ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+#define HM_OK 0
+#define HM_ERR_ARG (-1)
+#define HM_ERR_HIP (-2)

@@ -1,0 +1,129 @@
+// hm_hamer_forward: HAMER.forward_step (hamer.py:99-156) as one stream enqueue -- patch gather,
+// 1 + 4*depth + 1 MFMA GEMMs, LayerNorms, fused attention, the fp32 decoder head and the fused
+// MANO tail.  Host code only sequences kernels; no allocation, no sync (graph-capturable).
+#include "common.h"
+#include "hamer_hip_internal.h"
+
+int hm_split_head(const float* head, int ldh, float* pose6d, float* betas, float* cam, int B, hipStream_t s);
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, total;
+};
+
+Layout make_layout(const hm_hamer_weights& w, int B) {
+  const int gh = (w.img_h + 2 * w.pad - w.patch) / w.patch + 1, gw = (w.win_w + 2 * w.pad - w.patch) / w.patch + 1;
+  const size_t M = (size_t)B * gh * gw, D = w.embed_dim;
+  const size_t inner = (size_t)w.dec_heads * w.dec_dim_head;
+  const size_t dmax = (size_t)(w.dec_dim > w.dec_mlp ? w.dec_dim : w.dec_mlp);
+  Layout L;
+  size_t o = 0;
+  L.patches = o; o += align256(M * 3 * w.patch * w.patch * 2);
+  L.x = o; o += align256(M * D * 4);
+  L.h = o; o += align256(M * D * 2);
+  L.qkv = o; o += align256(M * 3 * D * 2);
+  L.att = o; o += align256(M * D * 2);
+  L.mlp = o; o += align256(M * (size_t)w.mlp_dim * 2);
+  L.kv = o; o += align256(M * (size_t)w.dec_depth * 2 * inner * 2);
+  L.xd = o; o += align256((size_t)B * w.dec_dim * 4);
+  L.hd = o; o += align256((size_t)B * w.dec_dim * 4);
+  L.t1 = o; o += align256((size_t)B * (inner > dmax ? inner : dmax) * 4);
+  L.t2 = o; o += align256((size_t)B * (inner > dmax ? inner : dmax) * 4);
+  L.head = o; o += align256((size_t)B * 112 * 4);
+  L.total = o;
+  return L;
+}
+
+int check_weights(const hm_hamer_weights* w) {
+  if (!w) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: null weights");
+  if (!w->blocks || !w->layers || !w->patch_w || !w->patch_b || !w->pos || !w->last_g || !w->last_b || !w->token0 ||
+      !w->kv_w || !w->head_w || !w->head_b)
+    return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: incomplete weights");
+  if (w->embed_dim % w->heads != 0) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: embed_dim % heads != 0");
+  return HM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t hm_hamer_workspace_bytes(const hm_hamer_weights* w, int B) {
+  if (!w || B <= 0) return 0;
+  return make_layout(*w, B).total;
+}
+
+#define HM_TRY(expr) do { int _rc = (expr); if (_rc != HM_OK) return _rc; } while (0)
+
+extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  HM_TRY(check_weights(w));
+  if (!img || !out || !workspace || B <= 0) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: bad arguments");
+  if (!out->pose6d || !out->betas || !out->cam || !out->rotmats || !out->verts || !out->joints || !out->cam_t || !out->kp2d)
+    return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: incomplete outputs");
+  const Layout L = make_layout(*w, B);
+  if (workspace_bytes < L.total) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: workspace too small");
+  if ((uintptr_t)workspace & 255) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: workspace must be 256-byte aligned");
+  char* ws = (char*)workspace;
+  const int gh = (w->img_h + 2 * w->pad - w->patch) / w->patch + 1, gw = (w->win_w + 2 * w->pad - w->patch) / w->patch + 1;
+  const int tokens = gh * gw, M = B * tokens, D = w->embed_dim, dt = w->dtype;
+  const int kpe = 3 * w->patch * w->patch;
+  float* x = (float*)(ws + L.x);
+  void *h = ws + L.h, *qkv = ws + L.qkv, *att = ws + L.att, *mlp = ws + L.mlp, *kv = ws + L.kv;
+
+  auto gemm = [&](const void* X, int ldx, const void* W, int K, int N, void* C, int ldc, const float* bias, int epi,
+                  const float* resid, int ldr, int rmod) {
+    hm_gemm_args g;
+    g.X = X; g.W = W; g.C = C; g.bias = bias; g.resid = resid;
+    g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldw = K; g.ldc = ldc; g.ldr = ldr; g.resid_mod = rmod;
+    g.epilogue = epi; g.dtype = dt;
+    return hm_gemm(&g, stream);
+  };
+
+  // ---- ViT backbone (vit.py:320-339)
+  HM_TRY(hm_patch_im2col(img, ws + L.patches, B, w->img_h, w->img_w_full, w->win_x0, w->win_w, w->patch, w->pad, dt, stream));
+  HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
+  const float scale = 1.0f / sqrtf((float)(D / w->heads));
+  for (int i = 0; i < w->depth; ++i) {
+    const hm_vit_block& b = w->blocks[i];
+    HM_TRY(hm_layernorm(x, b.ln1_g, b.ln1_b, h, dt, M, D, w->vit_eps, stream));
+    HM_TRY(gemm(h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
+    HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
+    HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, D, 0));
+    HM_TRY(hm_layernorm(x, b.ln2_g, b.ln2_b, h, dt, M, D, w->vit_eps, stream));
+    HM_TRY(gemm(h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0));
+    HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, D, 0));
+  }
+  void* tok = out->tokens ? out->tokens : h;
+  HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
+
+  // ---- decoder head (mano_head.py:61-95, pose_transformer.py:191-201)
+  const int dim = w->dec_dim, inner = w->dec_heads * w->dec_dim_head, ldkv = w->dec_depth * 2 * inner;
+  HM_TRY(gemm(tok, D, w->kv_w, D, ldkv, kv, ldkv, nullptr, HM_EPI_STORE, nullptr, 0, 0));
+  float *xd = (float*)(ws + L.xd), *hd = (float*)(ws + L.hd), *t1 = (float*)(ws + L.t1), *t2 = (float*)(ws + L.t2);
+  HM_TRY(hm_broadcast_rows(w->token0, xd, B, dim, stream));
+  const float dscale = 1.0f / sqrtf((float)w->dec_dim_head);
+  for (int i = 0; i < w->dec_depth; ++i) {
+    const hm_dec_layer& l = w->layers[i];
+    // self-attention over a single token: softmax == 1, so out = to_out(v) (pose_transformer.py:75-86)
+    HM_TRY(hm_layernorm(xd, l.ln0_g, l.ln0_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));
+    HM_TRY(hm_linear_f32(hd, dim, l.sa_v_w, dim, nullptr, nullptr, 0, t1, inner, B, inner, dim, 0, stream));
+    HM_TRY(hm_linear_f32(t1, inner, l.sa_out_w, inner, l.sa_out_b, xd, dim, xd, dim, B, dim, inner, 0, stream));
+    // cross-attention on the backbone tokens (pose_transformer.py:111-124)
+    HM_TRY(hm_layernorm(xd, l.ln1_g, l.ln1_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));
+    HM_TRY(hm_linear_f32(hd, dim, l.ca_q_w, dim, nullptr, nullptr, 0, t1, inner, B, inner, dim, 0, stream));
+    HM_TRY(hm_cross_attention(t1, kv, ldkv, i * 2 * inner, i * 2 * inner + inner, t2, B, tokens, w->dec_heads,
+                              w->dec_dim_head, dscale, dt, stream));
+    HM_TRY(hm_linear_f32(t2, inner, l.ca_out_w, inner, l.ca_out_b, xd, dim, xd, dim, B, dim, inner, 0, stream));
+    // feed-forward (pose_transformer.py:40-52)
+    HM_TRY(hm_layernorm(xd, l.ln2_g, l.ln2_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));
+    HM_TRY(hm_linear_f32(hd, dim, l.ff1_w, dim, l.ff1_b, nullptr, 0, t1, w->dec_mlp, B, w->dec_mlp, dim, 1, stream));
+    HM_TRY(hm_linear_f32(t1, w->dec_mlp, l.ff2_w, w->dec_mlp, l.ff2_b, xd, dim, xd, dim, B, dim, w->dec_mlp, 0, stream));
+  }
+  float* head = (float*)(ws + L.head);
+  HM_TRY(hm_linear_f32(xd, dim, w->head_w, dim, w->head_b, nullptr, 0, head, 112, B, 112, dim, 0, stream));
+  HM_TRY(hm_split_head(head, 112, out->pose6d, out->betas, out->cam, B, (hipStream_t)stream));
+  // ---- rot6d + MANO + projection (hamer.py:131-154)
+  return hm_mano_forward(&w->mano, out->pose6d, out->betas, out->cam, out->rotmats, out->verts, out->joints, out->cam_t,
+                         out->kp2d, B, w->focal_length, w->image_size, stream);
+}

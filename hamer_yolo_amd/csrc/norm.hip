@@ -1,0 +1,99 @@
+// nn.LayerNorm over the last dimension (vit.py:136,:144,:252 with eps 1e-6; the decoder's
+// PreNorm, pose_transformer.py:33-37 / t_cond_mlp.py:51-52, eps 1e-5).
+// HBM-bound: one wavefront per row, the row lives in registers (16-byte loads), two-pass
+// mean / variance in fp32, output written as bf16/fp16 (the next GEMM's operand) or f32.
+#include "common.h"
+#include "hamer_hip_internal.h"
+
+namespace {
+
+constexpr int MAXJ = 8;  // D <= 64 lanes * 4 floats * 8 = 2048
+
+template <class OutT>
+__device__ __forceinline__ void store4(OutT* p, f32x4_t v);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, f32x4_t v) { *(f32x4_t*)p = v; }
+template <>
+__device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4_t v) {
+  bf16x4_t o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+  *(bf16x4_t*)p = o;
+}
+template <>
+__device__ __forceinline__ void store4<_Float16>(_Float16* p, f32x4_t v) {
+  f16x4_t o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+  *(f16x4_t*)p = o;
+}
+
+template <class OutT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, OutT* __restrict__ out, int M,
+                                                        int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  f32x4_t v[MAXJ];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int i = lane * 4 + j * 256;
+    v[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (i < D) v[j] = *(const f32x4_t*)(xr + i);
+    s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int i = lane * 4 + j * 256;
+    if (i < D) {
+      const f32x4_t d = v[j] - mean;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  OutT* orow = out + (size_t)row * D;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int i = lane * 4 + j * 256;
+    if (i < D) {
+      const f32x4_t gm = *(const f32x4_t*)(gamma + i);
+      const f32x4_t bt = *(const f32x4_t*)(beta + i);
+      store4<OutT>(orow + i, (v[j] - mean) * rstd * gm + bt);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ vec, float* __restrict__ out,
+                                                             int B, int D) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)B * D) out[i] = vec[i % D];
+}
+
+}  // namespace
+
+extern "C" int hm_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype, int M,
+                            int D, float eps, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!x || !gamma || !beta || !out) return hm_set_error(HM_ERR_ARG, "hm_layernorm: null pointer");
+  if (M <= 0 || D <= 0 || D % 4 != 0 || D > 256 * MAXJ)
+    return hm_set_error(HM_ERR_ARG, "hm_layernorm: need 0 < D <= 2048, D % 4 == 0, M > 0");
+  dim3 grid((M + 3) / 4), block(256);
+  if (out_dtype == HM_DTYPE_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, s, x, gamma, beta, (__bf16*)out, M, D, eps);
+  else if (out_dtype == HM_DTYPE_F16)
+    hipLaunchKernelGGL(layernorm_kernel<_Float16>, grid, block, 0, s, x, gamma, beta, (_Float16*)out, M, D, eps);
+  else if (out_dtype == HM_OUT_F32)
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, gamma, beta, (float*)out, M, D, eps);
+  else
+    return hm_set_error(HM_ERR_ARG, "hm_layernorm: bad out_dtype");
+  return hm_check_launch("hm_layernorm");
+}
+
+extern "C" int hm_broadcast_rows(const float* vec, float* out, int B, int D, void* stream_) {
+  if (!vec || !out || B <= 0 || D <= 0) return hm_set_error(HM_ERR_ARG, "hm_broadcast_rows: bad arguments");
+  const size_t n = (size_t)B * D;
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, vec,
+                     out, B, D);
+  return hm_check_launch("hm_broadcast_rows");
+}

@@ -1,0 +1,22 @@
+// Error state of the C ABI: thread-local last-error string, never throws.
+#include <stdio.h>
+#include <string.h>
+#include "common.h"
+#include "hamer_hip_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int hm_set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+  return code;
+}
+
+int hm_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return HM_OK;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return HM_ERR_HIP;
+}
+
+extern "C" int hm_version(void) { return HM_VERSION; }
+extern "C" const char* hm_last_error_string(void) { return g_err; }

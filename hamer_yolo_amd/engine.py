@@ -1,0 +1,148 @@
+"""HamerEngine: device-resident HaMeR weights + one-call forward through libhamer_hip.
+
+Load time (host, once): GEMM matrices are converted to the 16-bit operand type and laid out
+[N][K] as nn.Linear stores them; the positional embedding is folded to ``pos[1:] + pos[0]``
+(vit.py:327); the six decoder ``to_kv`` matrices are stacked into one [6*1024][1280] GEMM
+operand; the V rows of the decoder's ``to_qkv`` are sliced out (one token: softmax == 1);
+the three read-out heads are stacked into one [112][1024] matrix with ``bias + init_*``.
+Run time: one ``hm_hamer_forward`` enqueue on the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as L
+from .ops import mano_model_struct
+from .synth import HamerConfig
+
+
+class HamerEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], mano: Dict[str, torch.Tensor],
+                 cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.bfloat16):
+        if not torch.cuda.is_available():
+            raise L.HipLibraryError("HamerEngine needs an MI355X (HIP device); there is no CPU fallback")
+        self.lib = L.load()
+        self.cfg = cfg or HamerConfig()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self._keep = []          # device tensors referenced by raw pointers
+        self._ws = None
+        self._ws_B = 0
+        v, d = self.cfg.vit, self.cfg.dec
+        sd = state_dict
+
+        def f32(t):
+            t = t.detach().to(self.device, torch.float32).contiguous()
+            self._keep.append(t)
+            return t
+
+        def w16(t):
+            t = t.detach().to(self.device, torch.float32).to(dtype).contiguous()
+            self._keep.append(t)
+            return t
+
+        D = v.embed_dim
+        self.blocks = (L.VitBlock * v.depth)()
+        for i in range(v.depth):
+            p = f"backbone.blocks.{i}."
+            b = self.blocks[i]
+            b.ln1_g, b.ln1_b = L.ptr(f32(sd[p + "norm1.weight"])), L.ptr(f32(sd[p + "norm1.bias"]))
+            b.ln2_g, b.ln2_b = L.ptr(f32(sd[p + "norm2.weight"])), L.ptr(f32(sd[p + "norm2.bias"]))
+            b.qkv_w, b.qkv_b = L.ptr(w16(sd[p + "attn.qkv.weight"])), L.ptr(f32(sd[p + "attn.qkv.bias"]))
+            b.proj_w, b.proj_b = L.ptr(w16(sd[p + "attn.proj.weight"])), L.ptr(f32(sd[p + "attn.proj.bias"]))
+            b.fc1_w, b.fc1_b = L.ptr(w16(sd[p + "mlp.fc1.weight"])), L.ptr(f32(sd[p + "mlp.fc1.bias"]))
+            b.fc2_w, b.fc2_b = L.ptr(w16(sd[p + "mlp.fc2.weight"])), L.ptr(f32(sd[p + "mlp.fc2.bias"]))
+        pos = sd["backbone.pos_embed"].to(torch.float32)
+        pos = pos[0, 1:] + pos[0, :1]
+
+        t = "mano_head.transformer."
+        inner = d.inner
+        self.layers = (L.DecLayer * d.depth)()
+        kv_rows = []
+        for i in range(d.depth):
+            p = f"{t}transformer.layers.{i}."
+            l = self.layers[i]
+            for j in range(3):
+                setattr(l, f"ln{j}_g", L.ptr(f32(sd[p + f"{j}.norm.weight"])))
+                setattr(l, f"ln{j}_b", L.ptr(f32(sd[p + f"{j}.norm.bias"])))
+            l.sa_v_w = L.ptr(f32(sd[p + "0.fn.to_qkv.weight"][2 * inner:3 * inner]))
+            l.sa_out_w, l.sa_out_b = L.ptr(f32(sd[p + "0.fn.to_out.0.weight"])), L.ptr(f32(sd[p + "0.fn.to_out.0.bias"]))
+            l.ca_q_w = L.ptr(f32(sd[p + "1.fn.to_q.weight"]))
+            l.ca_out_w, l.ca_out_b = L.ptr(f32(sd[p + "1.fn.to_out.0.weight"])), L.ptr(f32(sd[p + "1.fn.to_out.0.bias"]))
+            l.ff1_w, l.ff1_b = L.ptr(f32(sd[p + "2.fn.net.0.weight"])), L.ptr(f32(sd[p + "2.fn.net.0.bias"]))
+            l.ff2_w, l.ff2_b = L.ptr(f32(sd[p + "2.fn.net.3.weight"])), L.ptr(f32(sd[p + "2.fn.net.3.bias"]))
+            kv_rows.append(sd[p + "1.fn.to_kv.weight"].to(torch.float32))
+        token0 = sd[t + "to_token_embedding.bias"].to(torch.float32) + sd[t + "pos_embedding"].to(torch.float32)[0, 0]
+        head_w = torch.zeros(112, d.dim, dtype=torch.float32, device=sd["mano_head.decpose.weight"].device)
+        head_b = torch.zeros(112, dtype=torch.float32, device=head_w.device)
+        head_w[:96], head_w[96:106], head_w[106:109] = sd["mano_head.decpose.weight"], sd["mano_head.decshape.weight"], sd["mano_head.deccam.weight"]
+        head_b[:96] = sd["mano_head.decpose.bias"] + sd["mano_head.init_hand_pose"][0]
+        head_b[96:106] = sd["mano_head.decshape.bias"] + sd["mano_head.init_betas"][0]
+        head_b[106:109] = sd["mano_head.deccam.bias"] + sd["mano_head.init_cam"][0]
+
+        self.mano = {k: f32(mano[k]) for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")}
+        self.faces = mano.get("faces")
+
+        w = L.HamerWeights()
+        w.img_h, w.img_w_full = v.img_h, self.cfg.image_size
+        w.win_x0, w.win_w = (self.cfg.image_size - v.img_w) // 2, v.img_w      # hamer.py:119 x[:,:,:,32:-32]
+        w.patch, w.pad, w.embed_dim, w.depth, w.heads, w.mlp_dim = v.patch, v.pad, D, v.depth, v.heads, D * v.mlp_ratio
+        w.vit_eps = v.ln_eps
+        w.patch_w = L.ptr(w16(sd["backbone.patch_embed.proj.weight"].reshape(D, -1)))
+        w.patch_b = L.ptr(f32(sd["backbone.patch_embed.proj.bias"]))
+        w.pos = L.ptr(f32(pos))
+        w.blocks = C.cast(self.blocks, C.POINTER(L.VitBlock))
+        w.last_g, w.last_b = L.ptr(f32(sd["backbone.last_norm.weight"])), L.ptr(f32(sd["backbone.last_norm.bias"]))
+        w.dec_dim, w.dec_depth, w.dec_heads, w.dec_dim_head, w.dec_mlp = d.dim, d.depth, d.heads, d.dim_head, d.mlp_dim
+        w.dec_eps = d.ln_eps
+        w.token0 = L.ptr(f32(token0))
+        w.kv_w = L.ptr(w16(torch.cat(kv_rows, dim=0)))
+        w.layers = C.cast(self.layers, C.POINTER(L.DecLayer))
+        w.head_w, w.head_b = L.ptr(f32(head_w)), L.ptr(f32(head_b))
+        w.mano = mano_model_struct(self.mano)
+        w.focal_length, w.image_size = float(self.cfg.focal_length), float(self.cfg.image_size)
+        w.dtype = L.HM_DTYPE_BF16 if dtype == torch.bfloat16 else L.HM_DTYPE_F16
+        self.w = w
+        self.tokens = v.tokens
+        self.n_verts = int(self.mano["v_template"].shape[0])
+
+    # ------------------------------------------------------------------ run
+    def workspace(self, B: int) -> torch.Tensor:
+        if self._ws is None or self._ws_B < B:
+            n = self.lib.hm_hamer_workspace_bytes(C.byref(self.w), B)
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_B = B
+        return self._ws
+
+    def alloc_outputs(self, B: int, want_tokens: bool = False) -> Dict[str, torch.Tensor]:
+        dev, V = self.device, self.n_verts
+        o = {
+            "pose6d": torch.empty(B, 96, device=dev), "betas": torch.empty(B, 10, device=dev),
+            "pred_cam": torch.empty(B, 3, device=dev), "rotmats": torch.empty(B, 16, 3, 3, device=dev),
+            "pred_vertices": torch.empty(B, V, 3, device=dev), "pred_keypoints_3d": torch.empty(B, 21, 3, device=dev),
+            "pred_cam_t": torch.empty(B, 3, device=dev), "pred_keypoints_2d": torch.empty(B, 21, 2, device=dev),
+        }
+        if want_tokens:
+            o["tokens"] = torch.empty(B * self.tokens, self.cfg.vit.embed_dim, device=dev, dtype=self.dtype)
+        return o
+
+    def forward(self, img: torch.Tensor, out: Optional[Dict[str, torch.Tensor]] = None,
+                want_tokens: bool = False) -> Dict[str, torch.Tensor]:
+        """img: (B, 3, 256, 256) fp32 normalised crops on the device."""
+        if not img.is_cuda:
+            raise L.HipLibraryError("HamerEngine.forward takes a device tensor")
+        B = img.shape[0]
+        assert img.shape[1:] == (3, self.cfg.vit.img_h, self.cfg.image_size) and img.dtype == torch.float32
+        img = img.contiguous()
+        if out is None:
+            out = self.alloc_outputs(B, want_tokens)
+        ws = self.workspace(B)
+        ho = L.HamerOutputs(L.ptr(out["pose6d"]), L.ptr(out["betas"]), L.ptr(out["pred_cam"]), L.ptr(out["rotmats"]),
+                            L.ptr(out["pred_vertices"]), L.ptr(out["pred_keypoints_3d"]), L.ptr(out["pred_cam_t"]),
+                            L.ptr(out["pred_keypoints_2d"]), L.ptr(out.get("tokens")))
+        L.check(self.lib.hm_hamer_forward(C.byref(self.w), L.ptr(img), B, C.byref(ho), L.ptr(ws), ws.numel(),
+                                          L.current_stream()), "hm_hamer_forward")
+        return out

@@ -1,0 +1,129 @@
+"""ctypes binding of libhamer_hip.so (the C ABI declared in include/hamer_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the caller gets
+an exception (``HipLibraryError``).  PyTorch is used by the callers only to own device
+memory and the current HIP stream; only raw pointers and sizes cross this boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhamer_hip.so")
+
+HM_DTYPE_BF16, HM_DTYPE_F16, HM_OUT_F32 = 0, 1, 2
+HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
+    "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
+    "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward",
+]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+vp, fp = C.c_void_p, C.c_void_p  # every device pointer travels as void*
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("X", vp), ("W", vp), ("C", vp), ("bias", vp), ("resid", vp),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("ldx", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
+                ("resid_mod", C.c_int), ("epilogue", C.c_int), ("dtype", C.c_int)]
+
+
+class ManoModel(C.Structure):
+    _fields_ = [("v_template", vp), ("shapedirs", vp), ("posedirs", vp), ("J_regressor", vp), ("lbs_weights", vp),
+                ("n_verts", C.c_int)]
+
+
+class CropBox(C.Structure):
+    _fields_ = [("m0", C.c_double), ("m4", C.c_double), ("x0", C.c_int32), ("y0", C.c_int32),
+                ("flip", C.c_int32), ("reserved", C.c_int32)]
+
+
+class VitBlock(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "proj_w", "fc1_w", "fc2_w",
+                                  "qkv_b", "proj_b", "fc1_b", "fc2_b")]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "sa_v_w", "sa_out_w",
+                                  "sa_out_b", "ca_q_w", "ca_out_w", "ca_out_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
+
+
+class HamerWeights(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("img_h", "img_w_full", "win_x0", "win_w", "patch", "pad", "embed_dim", "depth",
+                                       "heads", "mlp_dim")] + \
+               [("vit_eps", C.c_float), ("patch_w", vp), ("patch_b", vp), ("pos", vp),
+                ("blocks", C.POINTER(VitBlock)), ("last_g", vp), ("last_b", vp)] + \
+               [(n, C.c_int) for n in ("dec_dim", "dec_depth", "dec_heads", "dec_dim_head", "dec_mlp")] + \
+               [("dec_eps", C.c_float), ("token0", vp), ("kv_w", vp), ("layers", C.POINTER(DecLayer)),
+                ("head_w", vp), ("head_b", vp), ("mano", ManoModel),
+                ("focal_length", C.c_float), ("image_size", C.c_float), ("dtype", C.c_int)]
+
+
+class HamerOutputs(C.Structure):
+    _fields_ = [(n, vp) for n in ("pose6d", "betas", "cam", "rotmats", "verts", "joints", "cam_t", "kp2d", "tokens")]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise HipLibraryError (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m hamer_yolo_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the hot path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    i, f, d = C.c_int, C.c_float, C.c_double
+    lib.hm_version.restype = i
+    lib.hm_last_error_string.restype = C.c_char_p
+    lib.hm_gemm.argtypes = [C.POINTER(GemmArgs), vp]
+    lib.hm_layernorm.argtypes = [vp, vp, vp, vp, i, i, i, f, vp]
+    lib.hm_vit_attention.argtypes = [vp, vp, i, i, i, i, f, i, vp]
+    lib.hm_patch_im2col.argtypes = [vp, vp, i, i, i, i, i, i, i, i, vp]
+    lib.hm_linear_f32.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, i, i, i, i, vp]
+    lib.hm_broadcast_rows.argtypes = [vp, vp, i, i, vp]
+    lib.hm_cross_attention.argtypes = [vp, vp, i, i, i, vp, i, i, i, i, f, i, vp]
+    lib.hm_mano_forward.argtypes = [C.POINTER(ManoModel), vp, vp, vp, vp, vp, vp, vp, vp, i, f, f, vp]
+    lib.hm_crop_box_from_bbox.argtypes = [d, d, d, i, i, C.POINTER(CropBox)]
+    lib.hm_crop_batch.argtypes = [vp, i, i, vp, vp, i, i, C.POINTER(C.c_float), C.POINTER(C.c_float), vp]
+    lib.hm_hamer_workspace_bytes.argtypes = [C.POINTER(HamerWeights), i]
+    lib.hm_hamer_workspace_bytes.restype = C.c_size_t
+    lib.hm_hamer_forward.argtypes = [C.POINTER(HamerWeights), vp, i, C.POINTER(HamerOutputs), vp, C.c_size_t, vp]
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}")
+        fn = getattr(lib, name)
+        if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes"):
+            fn.restype = i
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().hm_last_error_string().decode(errors="replace")
+        raise HipLibraryError(f"{what or 'libhamer_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,140 @@
+"""Thin tensor-level wrappers over the C ABI (one per exported kernel).
+
+Tensors are PyTorch-ROCm tensors used as device buffers; every function checks shapes on the
+host before handing raw pointers to the library, and raises on any library error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.bfloat16: L.HM_DTYPE_BF16, torch.float16: L.HM_DTYPE_F16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype not in _DT:
+        raise TypeError(f"16-bit operand expected (bfloat16/float16), got {t.dtype}")
+    return _DT[t.dtype]
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.HipLibraryError("libhamer_hip kernels take device tensors; there is no CPU path")
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = L.HM_EPI_STORE,
+         resid: Optional[torch.Tensor] = None, resid_mod: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epilogue(x @ w.T + bias); x (M,K), w (N,K) 16-bit row-major."""
+    _dev(x, w, bias, resid, out)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1 and x.dtype == w.dtype
+    f32_out = epilogue in (L.HM_EPI_RESID_F32, L.HM_EPI_F32)
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32 if f32_out else x.dtype)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    a = L.GemmArgs(L.ptr(x), L.ptr(w), L.ptr(out), L.ptr(bias), L.ptr(resid), M, N, K, x.stride(0), w.stride(0),
+                   out.stride(0), resid.stride(0) if resid is not None else 0, resid_mod, epilogue, _dt(x))
+    L.check(L.load().hm_gemm(C.byref(a), L.current_stream()), "hm_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype=torch.bfloat16) -> torch.Tensor:
+    _dev(x, gamma, beta)
+    M, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(M, D, device=x.device, dtype=out_dtype)
+    code = L.HM_OUT_F32 if out_dtype == torch.float32 else _DT[out_dtype]
+    L.check(L.load().hm_layernorm(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(out), code, M, D, eps, L.current_stream()),
+            "hm_layernorm")
+    return out
+
+
+def vit_attention(qkv: torch.Tensor, B: int, tokens: int, heads: int, head_dim: int, scale: float) -> torch.Tensor:
+    _dev(qkv)
+    assert qkv.shape == (B * tokens, 3 * heads * head_dim) and qkv.is_contiguous()
+    out = torch.empty(B * tokens, heads * head_dim, device=qkv.device, dtype=qkv.dtype)
+    L.check(L.load().hm_vit_attention(L.ptr(qkv), L.ptr(out), B, tokens, heads, head_dim, scale, _dt(qkv),
+                                      L.current_stream()), "hm_vit_attention")
+    return out
+
+
+def patch_im2col(img: torch.Tensor, x0: int, win_w: int, patch: int, pad: int, dtype=torch.bfloat16) -> torch.Tensor:
+    _dev(img)
+    B, Cc, H, Wf = img.shape
+    assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous()
+    gh, gw = (H + 2 * pad - patch) // patch + 1, (win_w + 2 * pad - patch) // patch + 1
+    out = torch.empty(B * gh * gw, 3 * patch * patch, device=img.device, dtype=dtype)
+    L.check(L.load().hm_patch_im2col(L.ptr(img), L.ptr(out), B, H, Wf, x0, win_w, patch, pad, _DT[dtype],
+                                     L.current_stream()), "hm_patch_im2col")
+    return out
+
+
+def linear_f32(x: torch.Tensor, w: torch.Tensor, bias=None, resid=None, act: int = 0) -> torch.Tensor:
+    _dev(x, w, bias, resid)
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    L.check(L.load().hm_linear_f32(L.ptr(x), x.stride(0), L.ptr(w), w.stride(0), L.ptr(bias), L.ptr(resid),
+                                   resid.stride(0) if resid is not None else 0, L.ptr(out), N, M, N, K, act,
+                                   L.current_stream()), "hm_linear_f32")
+    return out
+
+
+def cross_attention(q: torch.Tensor, kv: torch.Tensor, k_off: int, v_off: int, B: int, tokens: int, heads: int,
+                    dim_head: int, scale: float) -> torch.Tensor:
+    _dev(q, kv)
+    out = torch.empty(B, heads * dim_head, device=q.device, dtype=torch.float32)
+    L.check(L.load().hm_cross_attention(L.ptr(q), L.ptr(kv), kv.stride(0), k_off, v_off, L.ptr(out), B, tokens, heads,
+                                        dim_head, scale, _dt(kv), L.current_stream()), "hm_cross_attention")
+    return out
+
+
+def mano_model_struct(mp: dict) -> L.ManoModel:
+    return L.ManoModel(L.ptr(mp["v_template"]), L.ptr(mp["shapedirs"]), L.ptr(mp["posedirs"]), L.ptr(mp["J_regressor"]),
+                       L.ptr(mp["lbs_weights"]), int(mp["v_template"].shape[0]))
+
+
+def mano_forward(mp: dict, pose6d: torch.Tensor, betas: torch.Tensor, cam: torch.Tensor, focal: float = 5000.0,
+                 image_size: float = 256.0) -> dict:
+    """mp: device fp32 tensors keyed like synth.mano_params()."""
+    _dev(pose6d, betas, cam, *[mp[k] for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights")])
+    B, V, dev = pose6d.shape[0], mp["v_template"].shape[0], pose6d.device
+    o = {
+        "rotmats": torch.empty(B, 16, 3, 3, device=dev), "verts": torch.empty(B, V, 3, device=dev),
+        "joints": torch.empty(B, 21, 3, device=dev), "cam_t": torch.empty(B, 3, device=dev),
+        "kp2d": torch.empty(B, 21, 2, device=dev),
+    }
+    m = mano_model_struct(mp)
+    L.check(L.load().hm_mano_forward(C.byref(m), L.ptr(pose6d), L.ptr(betas), L.ptr(cam), L.ptr(o["rotmats"]),
+                                     L.ptr(o["verts"]), L.ptr(o["joints"]), L.ptr(o["cam_t"]), L.ptr(o["kp2d"]), B,
+                                     focal, image_size, L.current_stream()), "hm_mano_forward")
+    return o
+
+
+def crop_boxes(boxes, P: int = 256) -> torch.Tensor:
+    """boxes: iterable of (cx, cy, size, flip) -> uint8 host tensor holding hm_crop_box records."""
+    lib = L.load()
+    arr = (L.CropBox * len(boxes))()
+    for i, (cx, cy, size, flip) in enumerate(boxes):
+        L.check(lib.hm_crop_box_from_bbox(float(cx), float(cy), float(size), int(bool(flip)), P, C.byref(arr[i])),
+                "hm_crop_box_from_bbox")
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+
+
+def crop_batch(frame: torch.Tensor, boxes_rec: torch.Tensor, mean, std, P: int = 256) -> torch.Tensor:
+    """frame (H,W,3) uint8 BGR on device; boxes_rec: device uint8 tensor of hm_crop_box records."""
+    _dev(frame, boxes_rec)
+    H, W, _ = frame.shape
+    B = boxes_rec.numel() // C.sizeof(L.CropBox)
+    out = torch.empty(B, 3, P, P, device=frame.device, dtype=torch.float32)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean])
+    s3 = (C.c_float * 3)(*[float(v) for v in std])
+    L.check(L.load().hm_crop_batch(L.ptr(frame), H, W, L.ptr(boxes_rec), L.ptr(out), B, P, m3, s3, L.current_stream()),
+            "hm_crop_batch")
+    return out

@@ -1,0 +1,191 @@
+/* libhamer_hip: C ABI of the MI355X (gfx950) hand-mesh hot path.
+ *
+ * The reference (2646207530/hamer-yolo) has no FFI: its boundary is a set of Python call
+ * signatures.  Each entry point below replaces the PyTorch/cv2/smplx
+ * arithmetic behind one of those calls; the Python host layer (hamer_yolo_amd/) keeps the
+ * reference's names and argument meaning and binds these symbols with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory owned by the caller unless the name ends in _host;
+ *    the library allocates nothing persistent and keeps no reference after return;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), no internal sync;
+ *  - return value: 0 on success, negative library code otherwise (HM_ERR_*); the message is
+ *    available from hm_last_error_string() (thread-local); nothing throws across the ABI;
+ *  - matrices are row-major; "ld*" are leading dimensions in ELEMENTS;
+ *  - dtype selects the 16-bit GEMM operand type (bf16 or fp16, same MFMA rate).
+ */
+#ifndef HAMER_HIP_H
+#define HAMER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM_VERSION 100
+
+enum { HM_DTYPE_BF16 = 0, HM_DTYPE_F16 = 1 };
+
+/* GEMM epilogues */
+enum {
+  HM_EPI_STORE = 0,     /* C(16-bit) = acc + bias                                  */
+  HM_EPI_GELU = 1,      /* C(16-bit) = gelu_erf(acc + bias)        vit.py:82-87    */
+  HM_EPI_RESID_F32 = 2, /* C(f32)    = acc + bias + resid[m % resid_mod][n]        */
+  HM_EPI_F32 = 3,       /* C(f32)    = acc + bias                                  */
+  HM_EPI_SILU = 4       /* C(16-bit) = silu(acc + bias)      yolov7 common.py:114  */
+};
+
+typedef struct hm_gemm_args {
+  const void* X;      /* [M][ldx] 16-bit activations                                  */
+  const void* W;      /* [N][ldw] 16-bit weights (nn.Linear layout)                   */
+  void* C;            /* [M][ldc] 16-bit or f32 by epilogue                           */
+  const float* bias;  /* [N] or NULL                                                  */
+  const float* resid; /* [resid_mod or M][ldr] f32, HM_EPI_RESID_F32 only (may alias C) */
+  int M, N, K;
+  int ldx, ldw, ldc, ldr;
+  int resid_mod;      /* >0: residual row = m % resid_mod (positional embedding)      */
+  int epilogue;
+  int dtype;
+} hm_gemm_args;
+
+/* nn.Linear forward on MFMA: C = epilogue(X . W^T).  Replaces the aten::addmm calls behind
+ * Attention.qkv/.proj (vit.py:114,:124), Mlp.fc1/.fc2 (vit.py:83,:85), PatchEmbed.proj
+ * (vit.py:172, after hm_patch_im2col) and CrossAttention.to_kv (pose_transformer.py:114). */
+int hm_gemm(const hm_gemm_args* args, void* stream);
+
+/* nn.LayerNorm over the last dim (vit.py:136,:144,:252 eps 1e-6; t_cond_mlp.py:51-52 eps 1e-5).
+ * x [M][D] f32 -> out [M][D]; out_dtype: HM_DTYPE_BF16 / HM_DTYPE_F16 / HM_OUT_F32. */
+#define HM_OUT_F32 2
+int hm_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype,
+                 int M, int D, float eps, void* stream);
+
+/* Attention.forward core (vit.py:115-123): softmax(scale q k^T) v for `tokens`=192 keys.
+ * qkv [B*tokens][3*heads*head_dim] 16-bit, column = which*H*d + head*d + i (reshape at
+ * vit.py:112); out [B*tokens][heads*head_dim] 16-bit (head-major, vit.py:123). */
+int hm_vit_attention(const void* qkv, void* out, int B, int tokens, int heads, int head_dim, float scale,
+                     int dtype, void* stream);
+
+/* PatchEmbed.proj im2col (vit.py:168-176, called on x[:, :, :, 32:-32] at hamer.py:119):
+ * img [B][3][img_h][img_w_full] f32, window columns [x0, x0+win_w), conv k=patch, s=patch,
+ * zero pad `pad` -> patches [B*gh*gw][3*patch*patch] 16-bit, K order (c, ky, kx). */
+int hm_patch_im2col(const float* img, void* patches, int B, int img_h, int img_w_full, int x0, int win_w,
+                    int patch, int pad, int dtype, void* stream);
+
+/* Small f32 nn.Linear on f32-input MFMA: out[M][N] = act(x[M][K] . W[N][K]^T + bias) (+ resid).
+ * act: 0 none, 1 gelu_erf.  Decoder layers (pose_transformer.py:40-124) and the read-out
+ * heads (mano_head.py:93-95).  K % 16 == 0. */
+int hm_linear_f32(const float* x, int ldx, const float* W, int ldw, const float* bias, const float* resid, int ldr,
+                  float* out, int ldo, int M, int N, int K, int act, void* stream);
+
+/* out[b][:] = vec[:] for b < B (the zero-token embedding, pose_transformer.py:350-354). */
+int hm_broadcast_rows(const float* vec, float* out, int B, int D, void* stream);
+
+/* CrossAttention core for one query token (pose_transformer.py:117-123):
+ * q [B][heads*dim_head] f32; k,v rows b*tokens+t of kv (16-bit, ld = ldkv), k at column
+ * k_off + h*dim_head, v at v_off + h*dim_head; out [B][heads*dim_head] f32.  dim_head == 64. */
+int hm_cross_attention(const float* q, const void* kv, int ldkv, int k_off, int v_off, float* out, int B, int tokens,
+                       int heads, int dim_head, float scale, int dtype, void* stream);
+
+/* MANO-shaped model parameters (smplx.MANOLayer buffers; mano_wrapper.py:12-30). */
+typedef struct hm_mano_model {
+  const float* v_template;  /* [V][3]                */
+  const float* shapedirs;   /* [V][3][10]            */
+  const float* posedirs;    /* [135][3V]             */
+  const float* J_regressor; /* [16][V]               */
+  const float* lbs_weights; /* [V][16]               */
+  int n_verts;              /* V = 778               */
+} hm_mano_model;
+
+/* rot6d_to_rotmat (geometry.py:47-70) + MANO.forward (mano_wrapper.py:32-44 -> smplx lbs) +
+ * cam_t and perspective_projection (hamer.py:131-154), one workgroup per hand.
+ * pose6d [B][96], betas [B][10], cam [B][3] ->
+ * rotmats [B][16][3][3], verts [B][V][3], joints [B][21][3], cam_t [B][3], kp2d [B][21][2]. */
+int hm_mano_forward(const hm_mano_model* model, const float* pose6d, const float* betas, const float* cam,
+                    float* rotmats, float* verts, float* joints, float* cam_t, float* kp2d, int B,
+                    float focal_length, float image_size, void* stream);
+
+/* Batched affine bilinear crop (prepare_batch_bbox, infer.py:154-259; generate_image_patch_cv2,
+ * datasets/utils.py:318-376).  The per-box map is cv2.warpAffine's inverted matrix in its
+ * fixed-point form (source x = (x0 + rint(m0 * dst_x * 1024)) / 1024, 1/32-px bilinear). */
+typedef struct hm_crop_box {
+  double m0, m4;    /* d src_x / d dst_x, d src_y / d dst_y                         */
+  int32_t x0, y0;   /* rint(offset * 1024) + 16                                      */
+  int32_t flip;     /* 1: left hand, patch mirrored after the crop (infer.py:229-230) */
+  int32_t reserved;
+} hm_crop_box;
+
+/* HOST helper (no GPU work): box centre (cx, cy) and square side `size` in frame pixels ->
+ * hm_crop_box for a P x P patch (gen_trans_from_patch_cv, datasets/utils.py:82-129, rot 0). */
+int hm_crop_box_from_bbox(double cx, double cy, double size, int flip, int P, hm_crop_box* out);
+
+/* frame [H][W][3] u8 BGR (device); boxes [B] (device); out [B][3][P][P] f32 RGB,
+ * (x - mean_c) / std_c with mean/std in 0..255 units (infer.py:145-146,:235-238). */
+int hm_crop_batch(const uint8_t* frame, int H, int W, const hm_crop_box* boxes, float* out, int B, int P,
+                  const float* mean3_host, const float* std3_host, void* stream);
+
+/* Whole HAMER.forward_step (hamer.py:99-156) as one enqueue: see hm_hamer_forward below. */
+typedef struct hm_vit_block {
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;       /* 16-bit [N][K]                 */
+  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+} hm_vit_block;
+
+typedef struct hm_dec_layer {
+  const float *ln0_g, *ln0_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const float* sa_v_w;    /* rows [2*inner, 3*inner) of to_qkv.weight: [inner][dim]  */
+  const float *sa_out_w, *sa_out_b;
+  const float* ca_q_w;
+  const float *ca_out_w, *ca_out_b;
+  const float *ff1_w, *ff1_b, *ff2_w, *ff2_b;
+} hm_dec_layer;
+
+typedef struct hm_hamer_weights {
+  /* ViT (backbones/vit.py) */
+  int img_h, img_w_full, win_x0, win_w, patch, pad, embed_dim, depth, heads, mlp_dim;
+  float vit_eps;
+  const void* patch_w;       /* 16-bit [D][3*p*p]                                    */
+  const float* patch_b;
+  const float* pos;          /* f32 [tokens][D] = pos_embed[1:] + pos_embed[0]       */
+  const hm_vit_block* blocks; /* host array of `depth` entries                        */
+  const float *last_g, *last_b;
+  /* decoder (components/pose_transformer.py, heads/mano_head.py) */
+  int dec_dim, dec_depth, dec_heads, dec_dim_head, dec_mlp;
+  float dec_eps;
+  const float* token0;       /* f32 [dec_dim] = to_token_embedding.bias + pos_embedding */
+  const void* kv_w;          /* 16-bit [dec_depth*2*inner][embed_dim], layers stacked  */
+  const hm_dec_layer* layers; /* host array of `dec_depth` entries                     */
+  const float* head_w;       /* f32 [112][dec_dim]: decpose(96) | decshape(10) | deccam(3) | 3 zero rows */
+  const float* head_b;       /* f32 [112]: bias + init_{hand_pose,betas,cam}            */
+  hm_mano_model mano;
+  float focal_length, image_size;
+  int dtype;
+} hm_hamer_weights;
+
+typedef struct hm_hamer_outputs {
+  float* pose6d;   /* [B][96]  */
+  float* betas;    /* [B][10]  */
+  float* cam;      /* [B][3]   */
+  float* rotmats;  /* [B][16][3][3]: [:,0] = global_orient, [:,1:] = hand_pose */
+  float* verts;    /* [B][V][3]  */
+  float* joints;   /* [B][21][3] */
+  float* cam_t;    /* [B][3]     */
+  float* kp2d;     /* [B][21][2] */
+  void* tokens;    /* optional [B*tokens][D] 16-bit copy of the backbone output, or NULL */
+} hm_hamer_outputs;
+
+/* Bytes of workspace hm_hamer_forward needs for a batch of B crops. */
+size_t hm_hamer_workspace_bytes(const hm_hamer_weights* w, int B);
+
+/* img [B][3][img_h][img_w_full] f32 normalised crops -> outputs.  Enqueues ~300 kernels. */
+int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+int hm_version(void);
+const char* hm_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAMER_HIP_H */

@@ -1,0 +1,228 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (libhamer_hip.so via ctypes).
+
+Each HIP kernel is compared with the oracle's statement of the same step on the same seeded
+inputs.  16-bit outputs: the oracle rounds where the kernel rounds, so the residual
+difference is fp32 accumulation order (a value may flip one 16-bit ulp).  Integer / byte
+work (crop) must be bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hamer_yolo_amd import lib as L
+from hamer_yolo_amd import ops, synth
+from oracle import crop_ref
+from oracle import hamer_ref as R
+
+DEV = "cuda"
+
+
+def _u(name, shape, hw=1.0, seed=0, center=0.0):
+    return synth.uniform(name, shape, hw, center, seed=seed)
+
+
+def _ulp16(dtype):
+    return 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+
+
+# ------------------------------------------------------------------------------------ GEMM
+def test_gemm_exact_integers_asymmetric():
+    """Small-integer operands: every product and partial sum is exact in fp32, so the result must
+    be bit-exact whatever the accumulation order; W asymmetric to catch transposed writes."""
+    M, N, K = 192, 256, 128
+    x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+    w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+    ref = x @ w.t()
+    for dt in (torch.bfloat16, torch.float16):
+        out = ops.gemm(x.to(DEV, dt), w.to(DEV, dt), epilogue=L.HM_EPI_F32)
+        assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(384, 1280, 768), (192, 3840, 1280), (200, 132, 64), (64, 6144, 1280), (1, 4, 64)])
+def test_gemm_epilogues(M, N, K, dt):
+    x = _u("gx", (M, K), 1.0, seed=M).to(dt)
+    w = _u("gw", (N, K), 0.05, seed=N).to(dt)
+    bias = _u("gb", (N,), 0.5, seed=K)
+    resid = _u("gr", (M, N), 1.0, seed=3)
+    acc = x.float().double() @ w.float().double().t()
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV)
+    ulp = _ulp16(dt)
+    # f32 outputs
+    o = ops.gemm(xd, wd, bd, L.HM_EPI_F32).cpu().double()
+    np.testing.assert_allclose(o.numpy(), (acc + bias.double()).numpy(), atol=2e-5 * math.sqrt(K), rtol=1e-5)
+    o = ops.gemm(xd, wd, None, L.HM_EPI_F32).cpu().double()
+    np.testing.assert_allclose(o.numpy(), acc.numpy(), atol=2e-5 * math.sqrt(K), rtol=1e-5)
+    o = ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd).cpu().double()
+    np.testing.assert_allclose(o.numpy(), (acc + bias.double() + resid.double()).numpy(), atol=2e-5 * math.sqrt(K), rtol=1e-5)
+    # residual with row modulo (positional embedding) and in-place accumulate
+    if M % 4 == 0 and M >= 8:
+        mod = M // 4
+        o = ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd[:mod].contiguous(), resid_mod=mod).cpu().double()
+        ref = acc + bias.double() + resid[:mod].double().repeat(4, 1)
+        np.testing.assert_allclose(o.numpy(), ref.numpy(), atol=2e-5 * math.sqrt(K), rtol=1e-5)
+    buf = rd.clone()
+    ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=buf, out=buf)
+    np.testing.assert_allclose(buf.cpu().double().numpy(), (acc + bias.double() + resid.double()).numpy(),
+                               atol=2e-5 * math.sqrt(K), rtol=1e-5)
+    # 16-bit outputs
+    for epi, fn in ((L.HM_EPI_STORE, lambda t: t), (L.HM_EPI_GELU, lambda t: F.gelu(t)), (L.HM_EPI_SILU, lambda t: F.silu(t))):
+        ref = fn((acc + bias.double()).float())
+        o = ops.gemm(xd, wd, bd, epi).cpu().float()
+        np.testing.assert_allclose(o.numpy(), ref.numpy(), atol=1e-4 * math.sqrt(K) + 2e-3, rtol=2 * ulp)
+
+
+def test_gemm_rejects_bad_arguments():
+    x = torch.zeros(16, 96, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(16, 96, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(L.HipLibraryError):
+        ops.gemm(x, w)                       # K % 64 != 0
+    with pytest.raises(L.HipLibraryError):
+        ops.gemm(torch.zeros(16, 64), torch.zeros(16, 64))   # host tensors: no CPU path
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("D,eps", [(1280, 1e-6), (1024, 1e-5), (320, 1e-6), (256, 1e-5)])
+def test_layernorm(D, eps):
+    M = 197
+    x = _u("lnx", (M, D), 3.0, seed=D, center=0.5)
+    g, b = _u("lng", (D,), 0.1, seed=1, center=1.0), _u("lnb", (D,), 0.1, seed=2)
+    ref = F.layer_norm(x, (D,), g, b, eps)
+    o = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), eps, torch.float32).cpu()
+    np.testing.assert_allclose(o.numpy(), ref.numpy(), atol=2e-6, rtol=1e-5)
+    for dt in (torch.bfloat16, torch.float16):
+        o = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), eps, dt).cpu().float()
+        np.testing.assert_allclose(o.numpy(), ref.numpy(), atol=1e-6, rtol=_ulp16(dt))
+
+
+# ------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,heads", [(2, 16), (3, 4)])
+def test_vit_attention(B, heads, dt):
+    T, hd = 192, 80
+    qkv = _u("qkv", (B * T, 3 * heads * hd), 2.0, seed=heads).to(dt)
+    out = ops.vit_attention(qkv.to(DEV), B, T, heads, hd, hd ** -0.5).cpu().float()
+    q, k, v = qkv.float().reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * hd ** -0.5
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    ref = ((p.to(dt).float() @ v) / p.sum(-1, keepdim=True)).transpose(1, 2).reshape(B * T, heads * hd)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=2e-3 if dt == torch.bfloat16 else 3e-4, rtol=2 * _ulp16(dt))
+    # against the exact softmax (what the reference computes on these operands)
+    exact = (s.softmax(-1) @ v).transpose(1, 2).reshape(B * T, heads * hd)
+    np.testing.assert_allclose(out.numpy(), exact.numpy(), atol=1.5e-2 if dt == torch.bfloat16 else 2e-3, rtol=0)
+
+
+def test_vit_attention_peaked_rows():
+    """One key dominates each row (max far above the rest): exercises the max subtraction."""
+    B, heads, T, hd = 1, 2, 192, 80
+    qkv = _u("qkvp", (B * T, 3 * heads * hd), 0.5, seed=9)
+    qkv[:, :heads * hd] *= 8.0
+    qkv[17, heads * hd:2 * heads * hd] *= 12.0
+    qkv = qkv.to(torch.bfloat16)
+    out = ops.vit_attention(qkv.to(DEV), B, T, heads, hd, hd ** -0.5).cpu().float()
+    q, k, v = qkv.float().reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    exact = (((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v).transpose(1, 2).reshape(B * T, heads * hd)
+    assert torch.isfinite(out).all()
+    np.testing.assert_allclose(out.numpy(), exact.numpy(), atol=1.5e-2, rtol=0)
+
+
+# ------------------------------------------------------------------------------------ patch gather
+def test_patch_im2col_matches_conv_unfold():
+    B = 3
+    img = _u("img", (B, 3, 256, 256), 2.0, seed=4)
+    for dt in (torch.bfloat16, torch.float16):
+        pat = ops.patch_im2col(img.to(DEV), 32, 192, 16, 2, dt).cpu().float()
+        ref = F.unfold(img[:, :, :, 32:-32].to(dt).float(), kernel_size=16, stride=16, padding=2)  # (B, 768, 192)
+        ref = ref.transpose(1, 2).reshape(B * 192, 768)
+        assert torch.equal(pat, ref)
+
+
+# ------------------------------------------------------------------------------------ decoder pieces
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (5, 112, 1024), (33, 512, 256), (1, 256, 512)])
+def test_linear_f32(M, N, K):
+    x, w = _u("lx", (M, K), 1.0, seed=M), _u("lw", (N, K), K ** -0.5, seed=N)
+    b, r = _u("lb", (N,), 0.1, seed=1), _u("lr", (M, N), 1.0, seed=2)
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    ref = (x.double() @ w.double().t() + b.double())
+    np.testing.assert_allclose(ops.linear_f32(xd, wd, bd).cpu().numpy(), ref.float().numpy(), atol=3e-6 * math.sqrt(K), rtol=1e-5)
+    np.testing.assert_allclose(ops.linear_f32(xd, wd, bd, rd, act=1).cpu().numpy(),
+                               (F.gelu(ref.float()) + r).numpy(), atol=3e-6 * math.sqrt(K), rtol=1e-5)
+    np.testing.assert_allclose(ops.linear_f32(xd, wd).cpu().numpy(), (x.double() @ w.double().t()).float().numpy(),
+                               atol=3e-6 * math.sqrt(K), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_cross_attention(dt):
+    B, T, heads, dh, layers = 5, 192, 8, 64, 3
+    inner = heads * dh
+    q = _u("caq", (B, inner), 2.0, seed=1)
+    kv = _u("cakv", (B * T, layers * 2 * inner), 1.5, seed=2).to(dt)
+    li = 1
+    out = ops.cross_attention(q.to(DEV), kv.to(DEV), li * 2 * inner, li * 2 * inner + inner, B, T, heads, dh, dh ** -0.5).cpu()
+    kvf = kv.float().reshape(B, T, layers, 2, heads, dh)
+    k, v = kvf[:, :, li, 0].permute(0, 2, 1, 3), kvf[:, :, li, 1].permute(0, 2, 1, 3)   # (B,h,T,dh)
+    a = ((q.reshape(B, heads, 1, dh) @ k.transpose(-1, -2)) * dh ** -0.5).softmax(-1)
+    ref = (a @ v).reshape(B, inner)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=2e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------ MANO tail
+def test_mano_forward_vs_oracle_and_manopth(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "mano_manopth.npz"))
+    mp = synth.mano_params(seed=int(g["mano_seed"]))
+    mpd = {k: v.to(DEV) for k, v in mp.items() if v.dtype == torch.float32}
+    B = 37
+    pose6d = _u("m6", (B, 96), 1.0, seed=7)
+    betas = _u("mb", (B, 10), 2.0, seed=8)
+    cam = _u("mc", (B, 3), 0.2, seed=9) + torch.tensor([0.9, 0.0, 0.0])
+    o = ops.mano_forward(mpd, pose6d.to(DEV), betas.to(DEV), cam.to(DEV))
+    Rr = R.rot6d_to_rotmat(pose6d).view(B, 16, 3, 3)
+    verts, joints = R.mano_forward(mp, betas, Rr)
+    cam_t = torch.stack([cam[:, 1], cam[:, 2], 2 * 5000.0 / (256.0 * cam[:, 0] + 1e-9)], -1)
+    kp2d = R.perspective_projection(joints, cam_t, torch.full((B, 2), 5000.0 / 256.0))
+    np.testing.assert_allclose(o["rotmats"].cpu().numpy(), Rr.numpy(), atol=2e-6)
+    np.testing.assert_allclose(o["verts"].cpu().numpy(), verts.numpy(), atol=3e-6)
+    np.testing.assert_allclose(o["joints"].cpu().numpy(), joints.numpy(), atol=3e-6)
+    np.testing.assert_allclose(o["cam_t"].cpu().numpy(), cam_t.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(o["kp2d"].cpu().numpy(), kp2d.numpy(), atol=1e-5, rtol=1e-5)
+    # golden: the in-tree manopth layer on the same parameters.  Drive the kernel with a 6-D pose
+    # equal to the first two columns of the golden rotation matrices.
+    Rg = torch.from_numpy(g["rotmats"])                       # (4,16,3,3)
+    six = torch.cat([Rg[..., 0], Rg[..., 1]], dim=-1).reshape(4, 96)
+    o = ops.mano_forward(mpd, six.to(DEV), torch.from_numpy(g["betas"]).to(DEV), cam[:4].to(DEV))
+    np.testing.assert_allclose(o["rotmats"].cpu().numpy(), g["rotmats"], atol=3e-6)
+    np.testing.assert_allclose(o["verts"].cpu().numpy(), g["verts"], atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------ crop (byte-exact)
+def test_crop_batch_bit_exact_vs_oracle():
+    H, W = 540, 960
+    frame = (synth._hash_u32(torch.arange(H * W * 3, dtype=torch.int64), 77) >> 24).to(torch.uint8).reshape(H, W, 3)
+    dets = [["right", [100.0, 120.0, 260.0, 300.0]], ["left", [500.0, 200.0, 640.0, 330.0]],
+            ["left", [-20.0, -30.0, 90.0, 80.0]], ["right", [880.0, 470.0, 1000.0, 560.0]], ["right", [300.5, 100.25, 420.75, 260.5]]]
+    mean = 255.0 * np.array([0.485, 0.456, 0.406]); std = 255.0 * np.array([0.229, 0.224, 0.225])
+    ref = crop_ref.prepare_batch_bbox(frame.numpy(), dets, mean, std)
+    boxes = []
+    for label, (x1, y1, x2, y2) in dets:
+        cx, cy, S = crop_ref.bbox_to_center_size(x1, y1, x2, y2)
+        boxes.append((cx, cy, S, label != "right"))
+    rec = ops.crop_boxes(boxes)
+    out = ops.crop_batch(frame.to(DEV), rec.to(DEV), mean, std).cpu().numpy()
+    assert out.shape == ref["img"].shape
+    assert np.array_equal(out, ref["img"]), f"max diff {np.abs(out - ref['img']).max()}"
+
+
+def test_crop_identity_sampling():
+    """A 256-px box centred on an integer pixel samples source pixels exactly (SURVEY 8a KAT)."""
+    H, W = 400, 500
+    frame = (synth._hash_u32(torch.arange(H * W * 3, dtype=torch.int64), 5) >> 24).to(torch.uint8).reshape(H, W, 3)
+    rec = ops.crop_boxes([(250.0, 200.0, 256.0, False)])
+    out = ops.crop_batch(frame.to(DEV), rec.to(DEV), [0, 0, 0], [1, 1, 1]).cpu()
+    src = frame[200 - 128:200 + 128, 250 - 128:250 + 128].permute(2, 0, 1).float().flip(0)   # BGR -> RGB
+    assert torch.equal(out[0], src)

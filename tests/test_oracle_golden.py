@@ -1,0 +1,60 @@
+"""CPU: the oracle restatement against fixtures produced by the reference's own modules
+(tools/gen_golden.py, run in the build container)."""
+import os
+
+import numpy as np
+import torch
+
+from hamer_yolo_amd import synth
+from oracle import hamer_ref as R
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_tiny_hamer_matches_reference_modules(golden_dir):
+    g = _load(golden_dir, "hamer_tiny.npz")
+    cfg = synth.tiny_config()
+    sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]), bf16_representable=bool(g["bf16_representable"]))
+    img = synth.normalize_crops(synth.crops_u8(3, seed0=int(g["crop_seed0"])))
+    with torch.no_grad():
+        feats = R.vit_forward(sd, img[:, :, :, 32:-32], cfg.vit)
+        tok = R.decoder_forward(sd, feats, cfg.dec)
+        pose, betas, cam = R.mano_head_forward(sd, feats, cfg.dec)
+        rot = R.rot6d_to_rotmat(pose).view(3, 16, 3, 3)
+    np.testing.assert_allclose(feats.numpy(), g["tokens"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(tok.numpy(), g["token_out"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(pose.numpy(), g["pose6d"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(betas.numpy(), g["betas"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(cam.numpy(), g["cam"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(rot.numpy(), g["rotmats"], atol=2e-5, rtol=0)
+
+
+def test_geometry_matches_reference(golden_dir):
+    g = _load(golden_dir, "geometry.npz")
+    rot = R.rot6d_to_rotmat(torch.from_numpy(g["x6"]))
+    np.testing.assert_allclose(rot.numpy(), g["rotmat"], atol=1e-6, rtol=0)
+    proj = R.perspective_projection(torch.from_numpy(g["pts"]), torch.from_numpy(g["tr"]), torch.from_numpy(g["fl"]))
+    np.testing.assert_allclose(proj.numpy(), g["proj"], atol=1e-5, rtol=0)
+
+
+def test_mano_lbs_matches_manopth(golden_dir):
+    g = _load(golden_dir, "mano_manopth.npz")
+    mp = synth.mano_params(seed=int(g["mano_seed"]))
+    verts, joints = R.mano_forward(mp, torch.from_numpy(g["betas"]), torch.from_numpy(g["rotmats"]))
+    np.testing.assert_allclose(verts.numpy(), g["verts"], atol=2e-6, rtol=0)
+    # manopth's 16 posed joints are in the same openpose order; its finger tips use other
+    # vertex ids (manolayer.py:252-253), so compare the 16 regressed joints only.
+    jm = g["joints16_tips_manopth"]
+    non_tip = [i for i, j in enumerate(R.MANO_JOINT_MAP) if j < 16]
+    np.testing.assert_allclose(joints.numpy()[:, non_tip], jm[:, non_tip], atol=2e-6, rtol=0)
+    tips = [i for i, j in enumerate(R.MANO_JOINT_MAP) if j >= 16]
+    np.testing.assert_allclose(joints.numpy()[:, tips], verts.numpy()[:, R.MANO_TIP_VERTS], atol=0, rtol=0)
+
+
+def test_mano_rest_pose_is_template():
+    mp = synth.mano_params(seed=2)
+    eye = torch.eye(3).expand(2, 16, 3, 3).contiguous()
+    verts, joints = R.mano_forward(mp, torch.zeros(2, 10), eye)
+    np.testing.assert_allclose(verts.numpy(), mp["v_template"][None].expand(2, -1, -1).numpy(), atol=1e-6)
