@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- hands/sec of the HaMeR hot path on MI355X (BASELINE.json configs[1]).
+
+A step = one forward of hm_hamer_forward (patch gather, ViT-H/16 backbone, transformer-decoder
+MANO head, rot6d + MANO LBS + projection) over one batch of 64 synthetic 256x256 crops that are
+already resident in HBM, bf16 MFMA GEMMs, detector bypassed.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank processes its own 64-crop shard (weak
+scaling); RCCL carries the one-off weight broadcast and the per-step gather of per-hand MANO
+parameters to rank 0.
+
+Prints ONE JSON line on rank 0 (see the field list in DESIGN.md section "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hamer_yolo_amd import lib as L  # noqa: E402
+from hamer_yolo_amd import shard, synth  # noqa: E402
+from hamer_yolo_amd.engine import HamerEngine  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+EPI_NAMES = {0: "store", 1: "gelu", 2: "resid_f32", 3: "f32", 4: "silu"}
+
+
+def flops_per_hand(cfg: synth.HamerConfig) -> dict:
+    v, d = cfg.vit, cfg.dec
+    T, D, H = v.tokens, v.embed_dim, v.embed_dim * v.mlp_ratio
+    blk = 2 * T * D * 3 * D + 2 * 2 * T * T * D + 2 * T * D * D + 2 * 2 * T * D * H
+    patch = 2 * T * 3 * v.patch * v.patch * D
+    kv = 2 * T * d.context_dim * d.depth * 2 * d.inner
+    return {"vit": patch + v.depth * blk, "decoder_kv": kv, "total_mfma": patch + v.depth * blk + kv}
+
+
+def host_threads() -> int:
+    """Host cores this process may really use: HAMER_CPU_THREADS, else the cgroup CPU quota,
+    else min(affinity, 16) (a one-GPU box's share of the host is 16 cores)."""
+    if os.environ.get("HAMER_CPU_THREADS"):
+        return max(1, int(os.environ["HAMER_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfg, sd_dev, mano_cpu, seconds: float = 12.0):
+    """The oracle (CPU restatement of the reference path, fp32 PyTorch) timed on the host cores."""
+    from oracle import hamer_ref as R
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    sd = {k: v.float().cpu() for k, v in sd_dev.items()}
+    B = 8
+    img = synth.normalize_crops(synth.crops_u8(B, seed0=0))
+    with torch.no_grad():
+        R.hamer_forward(sd, mano_cpu, img[:1], cfg)      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            R.hamer_forward(sd, mano_cpu, img, cfg)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 6:
+                break
+    return {"value": round(n * B / dt, 3), "unit": "hands/s", "cores": threads, "kind": "port",
+            "sample": f"{n} forwards of B={B} crops (ViT-H/16 + decoder + MANO), fp32 torch CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE config: 64)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    rank, local, world = shard.init_distributed("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = torch.distributed
+    cfg = synth.HamerConfig()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    B = args.batch
+
+    # weights: rank 0 draws the synthetic checkpoint, RCCL broadcasts it
+    sd0 = synth.hamer_state_dict(cfg, seed=0, device=dev, bf16_representable=True) if rank == 0 else None
+    if world > 1:
+        meta =[{k: tuple(v.shape) for k, v in sd0.items()}] if rank == 0 else [None]
+        dist.broadcast_object_list(meta, src=0)
+        sd = shard.broadcast_state_dict(sd0, list(meta[0].keys()), meta[0], dev, src=0)
+    else:
+        sd = sd0
+    mano_cpu = synth.mano_params(seed=0)
+    eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype)
+
+    # this rank's shard of the global crop set (seeds rank*B .. rank*B+B-1), resident in HBM
+    img = synth.normalize_crops(synth.crops_u8(B, seed0=rank * B)).to(dev)
+    out = eng.alloc_outputs(B)
+    eng.workspace(B)
+
+    def step():
+        eng.forward(img, out)
+        if world > 1:
+            shard.gather_mano(shard.pack_mano(out), dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out["pred_vertices"]).all()
+
+    res = None
+    if rank == 0:
+        hands = world * B * args.steps
+        fl = flops_per_hand(cfg)
+        res = {
+            "metric": "hands/sec (HaMeR ViT-H/16 + decoder + MANO forward; detector bypassed)",
+            "value": round(hands / elapsed, 2), "unit": "hands/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=64 synthetic 256x256 crops per GPU, HaMeR ViT-H/16 "
+                                   "+ 6-layer decoder + MANO, 16-bit MFMA, crops resident in HBM",
+                       "batch_per_gpu": B, "global_batch": world * B, "weights": "seeded random-init (bf16-representable)",
+                       "parallelism": f"crop-shard x{world}", "mfma_gflop_per_hand": round(fl["total_mfma"] / 1e9, 2)},
+            "model_mfma_frac": round(hands / elapsed * fl["total_mfma"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+        }
+
+    # ---- roofline of the dominant kernel (the MFMA GEMM), HIP events on the launch stream
+    if rank == 0 and not args.no_roofline:
+        nprof = min(args.steps, 5)
+        with L.profile(capacity=nprof * 512) as prof:
+            for _ in range(nprof):
+                eng.forward(img, out)
+            torch.cuda.synchronize()
+        by_kind, gemm_fl, gemm_ms, per = {}, 0.0, 0.0, {}
+        for kind, epi, M, N, K, ms in prof.records:
+            by_kind[kind] = by_kind.get(kind, 0.0) + ms
+            if kind == "gemm":
+                gemm_fl += 2.0 * M * N * K
+                gemm_ms += ms
+                e = per.setdefault(EPI_NAMES[epi], [0, 0.0, 0.0])
+                e[0] += 1; e[1] += ms; e[2] += 2.0 * M * N * K
+        n_gemm = sum(v[0] for v in per.values())
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        res["roofline"] = {
+            "kernel": "gemm_tn_kernel (all epilogues)", "bound": "mfma", "achieved": round(achieved, 2),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n_gemm // nprof, "avg_launch_ms": round(gemm_ms / n_gemm, 5),
+            "flop_per_launch": round(gemm_fl / n_gemm),
+            "per_epilogue": {k: {"launches_per_step": v[0] // nprof, "avg_ms": round(v[1] / v[0], 5),
+                                 "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in per.items()},
+            "ms_per_step_by_kernel": {k: round(v / nprof, 4) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
+            "timing": f"hipEvent pairs around every launch, separate pass of {nprof} steps after the timed region",
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, sd, mano_cpu)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

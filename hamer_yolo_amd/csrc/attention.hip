@@ -154,6 +154,7 @@ extern "C" int hm_vit_attention(const void* qkv, void* out, int B, int tokens, i
   if (tokens != T || head_dim != HD)
     return hm_set_error(HM_ERR_ARG, "hm_vit_attention: built for 192 tokens and head_dim 80 (ViT-H/16 on 256x192)");
   if (((uintptr_t)qkv | (uintptr_t)out) & 15) return hm_set_error(HM_ERR_ARG, "hm_vit_attention: 16-byte alignment");
+  HmProfScope prof(HM_K_ATTENTION, 0, B, heads, head_dim, s);
   if (dtype == HM_DTYPE_BF16) return launch_att<TBf16>(qkv, out, B, heads, scale, s);
   if (dtype == HM_DTYPE_F16) return launch_att<TF16>(qkv, out, B, heads, scale, s);
   return hm_set_error(HM_ERR_ARG, "hm_vit_attention: bad dtype");

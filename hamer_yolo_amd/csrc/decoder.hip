@@ -126,6 +126,7 @@ extern "C" int hm_linear_f32(const float* x, int ldx, const float* W, int ldw, c
   if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)resid) & 15)
     return hm_set_error(HM_ERR_ARG, "hm_linear_f32: pointers must be 16-byte aligned");
   dim3 grid((N + 15) / 16, (M + 15) / 16), block(256);
+  HmProfScope prof(HM_K_LINEAR_F32, act, M, N, K, (hipStream_t)stream_);
   hipLaunchKernelGGL(linear_f32_kernel, grid, block, 0, (hipStream_t)stream_, x, ldx, W, ldw, bias, resid, ldr, out, ldo,
                      M, N, K, act);
   return hm_check_launch("hm_linear_f32");
@@ -140,6 +141,7 @@ extern "C" int hm_cross_attention(const float* q, const void* kv, int ldkv, int 
     return hm_set_error(HM_ERR_ARG, "hm_cross_attention: kv rows must be 16-byte aligned");
   dim3 grid((B * heads + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream_;
+  HmProfScope prof(HM_K_CROSS_ATTN, 0, B, tokens, heads, s);
   if (dtype == HM_DTYPE_BF16)
     hipLaunchKernelGGL(cross_attention_kernel<__bf16>, grid, block, 0, s, q, (const __bf16*)kv, ldkv, k_off, v_off, out, B, tokens, heads, scale);
   else if (dtype == HM_DTYPE_F16)

@@ -172,6 +172,7 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
     return hm_set_error(HM_ERR_ARG, "hm_gemm: residual epilogue needs resid and ldr >= N, ldr % 4 == 0");
   if (((uintptr_t)g.X | (uintptr_t)g.W | (uintptr_t)g.C | (uintptr_t)g.bias | (uintptr_t)g.resid) & 15)
     return hm_set_error(HM_ERR_ARG, "hm_gemm: pointers must be 16-byte aligned");
+  HmProfScope prof(HM_K_GEMM, g.epilogue, g.M, g.N, g.K, stream);
   if (g.dtype == HM_DTYPE_BF16) return launch_t<TBf16>(g, stream);
   if (g.dtype == HM_DTYPE_F16) return launch_t<TF16>(g, stream);
   return hm_set_error(HM_ERR_ARG, "hm_gemm: dtype must be HM_DTYPE_BF16 or HM_DTYPE_F16");

@@ -175,6 +175,7 @@ extern "C" int hm_mano_forward(const hm_mano_model* model, const float* pose6d, 
     return hm_set_error(HM_ERR_ARG, "hm_mano_forward: n_verts must be in (744, 800] (MANO has 778)");
   if (!model->v_template || !model->shapedirs || !model->posedirs || !model->J_regressor || !model->lbs_weights)
     return hm_set_error(HM_ERR_ARG, "hm_mano_forward: incomplete model");
+  HmProfScope prof(HM_K_MANO, 0, B, model->n_verts, 0, (hipStream_t)stream_);
   hipLaunchKernelGGL(mano_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, *model, pose6d, betas, cam, rotmats, verts,
                      joints, cam_t, kp2d, focal_length, image_size);
   return hm_check_launch("hm_mano_forward");

@@ -79,6 +79,7 @@ extern "C" int hm_layernorm(const float* x, const float* gamma, const float* bet
   if (M <= 0 || D <= 0 || D % 4 != 0 || D > 256 * MAXJ)
     return hm_set_error(HM_ERR_ARG, "hm_layernorm: need 0 < D <= 2048, D % 4 == 0, M > 0");
   dim3 grid((M + 3) / 4), block(256);
+  HmProfScope prof(HM_K_LAYERNORM, out_dtype, M, D, 0, s);
   if (out_dtype == HM_DTYPE_BF16)
     hipLaunchKernelGGL(layernorm_kernel<__bf16>, grid, block, 0, s, x, gamma, beta, (__bf16*)out, M, D, eps);
   else if (out_dtype == HM_DTYPE_F16)

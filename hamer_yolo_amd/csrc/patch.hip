@@ -101,6 +101,7 @@ extern "C" int hm_crop_batch(const uint8_t* frame, int H, int W, const hm_crop_b
   if (!frame || !boxes || !out || !mean3_host || !std3_host) return hm_set_error(HM_ERR_ARG, "hm_crop_batch: null pointer");
   if (H <= 0 || W <= 0 || B <= 0 || P <= 0 || B > 65535) return hm_set_error(HM_ERR_ARG, "hm_crop_batch: bad sizes");
   dim3 grid((P * P + 255) / 256, B), block(256);
+  HmProfScope prof(HM_K_CROP, 0, B, P, P, (hipStream_t)stream_);
   hipLaunchKernelGGL(crop_kernel, grid, block, 0, (hipStream_t)stream_, frame, H, W, boxes, out, P, mean3_host[0],
                      mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   return hm_check_launch("hm_crop_batch");
@@ -115,6 +116,7 @@ extern "C" int hm_patch_im2col(const float* img, void* patches, int B, int img_h
   const size_t total = (size_t)B * gh * gw * (3 * patch * patch / 8);
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream_;
+  HmProfScope prof(HM_K_IM2COL, 0, B, gh * gw, 3 * patch * patch, s);
   if (dtype == HM_DTYPE_BF16)
     hipLaunchKernelGGL(im2col_kernel<__bf16>, grid, block, 0, s, img, (__bf16*)patches, B, img_h, img_w_full, x0, win_w, patch, pad, gh, gw);
   else if (dtype == HM_DTYPE_F16)

@@ -18,8 +18,9 @@ HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
     "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
-    "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward",
+    "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
 ]
+KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
 
 class HipLibraryError(RuntimeError):
@@ -67,6 +68,10 @@ class HamerWeights(C.Structure):
                 ("focal_length", C.c_float), ("image_size", C.c_float), ("dtype", C.c_int)]
 
 
+class ProfRecord(C.Structure):
+    _fields_ = [("kind", C.c_int), ("epilogue", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ms", C.c_float)]
+
+
 class HamerOutputs(C.Structure):
     _fields_ = [(n, vp) for n in ("pose6d", "betas", "cam", "rotmats", "verts", "joints", "cam_t", "kp2d", "tokens")]
 
@@ -103,6 +108,9 @@ def load() -> C.CDLL:
     lib.hm_hamer_workspace_bytes.argtypes = [C.POINTER(HamerWeights), i]
     lib.hm_hamer_workspace_bytes.restype = C.c_size_t
     lib.hm_hamer_forward.argtypes = [C.POINTER(HamerWeights), vp, i, C.POINTER(HamerOutputs), vp, C.c_size_t, vp]
+    lib.hm_prof_begin.argtypes = [i]
+    lib.hm_prof_collect.argtypes = [C.POINTER(ProfRecord), i]
+    lib.hm_prof_end.argtypes = []
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise HipLibraryError(f"{LIB_PATH} does not export {name}")
@@ -127,3 +135,31 @@ def ptr(t) -> int:
 def current_stream() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+class profile:
+    """Context manager: per-launch HIP-event timings of every library kernel launched inside."""
+
+    def __init__(self, capacity: int = 1 << 16):
+        self.capacity = capacity
+        self.records = []
+
+    def __enter__(self):
+        check(load().hm_prof_begin(self.capacity), "hm_prof_begin")
+        return self
+
+    def collect(self):
+        buf = (ProfRecord * self.capacity)()
+        n = load().hm_prof_collect(buf, self.capacity)
+        if n < 0:
+            check(n, "hm_prof_collect")
+        self.records += [(KIND_NAMES[r.kind], r.epilogue, r.M, r.N, r.K, r.ms) for r in buf[:n]]
+        return self.records
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                self.collect()
+        finally:
+            load().hm_prof_end()
+        return False

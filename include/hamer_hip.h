@@ -182,6 +182,14 @@ size_t hm_hamer_workspace_bytes(const hm_hamer_weights* w, int B);
 int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Optional per-launch timing (HIP events on the launch stream); kinds below. */
+enum { HM_K_GEMM = 0, HM_K_LAYERNORM = 1, HM_K_ATTENTION = 2, HM_K_IM2COL = 3, HM_K_LINEAR_F32 = 4,
+       HM_K_CROSS_ATTN = 5, HM_K_MANO = 6, HM_K_CROP = 7, HM_K_CONV = 8, HM_K_OTHER = 9 };
+typedef struct hm_prof_record { int kind, epilogue, M, N, K; float ms; } hm_prof_record;
+int hm_prof_begin(int capacity);                        /* allocate 2*capacity events, start logging */
+int hm_prof_collect(hm_prof_record* out_host, int cap); /* sync, copy records, clear; returns count   */
+int hm_prof_end(void);                                  /* stop logging, destroy the events           */
+
 int hm_version(void);
 const char* hm_last_error_string(void);
 
