@@ -1,0 +1,194 @@
+"""CPU tests: host-side mirror of the reference interface, C-ABI export surface, crop oracle KATs,
+and the world_size-2 shard path on gloo.  No GPU compute is launched here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from hamer_yolo_amd import lib as L
+from hamer_yolo_amd import shard, synth
+from hamer_yolo_amd.hamer.configs import get_config
+from hamer_yolo_amd.hamer.datasets.utils import expand_to_aspect_ratio, gen_trans_from_patch_cv
+from hamer_yolo_amd.hamer.utils.renderer import cam_crop_to_full, custom_cam_crop_to_full
+from oracle import crop_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hamer_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(hm_[a-z0-9_]+)\s*\(", hdr)))
+    assert "hm_gemm" in declared and "hm_hamer_forward" in declared
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/hamer_hip.h but not exported"
+    assert lib.hm_version() == 100
+
+
+def test_abi_rejects_bad_arguments_without_gpu():
+    lib = L.load()
+    assert lib.hm_gemm(None, None) != 0
+    assert b"null" in lib.hm_last_error_string()
+    a = L.GemmArgs(1, 1, 1, None, None, 16, 16, 96, 96, 96, 16, 0, 0, 0, 0)
+    assert lib.hm_gemm(C.byref(a), None) != 0 and b"multiple of 64" in lib.hm_last_error_string()
+    assert lib.hm_vit_attention(16, 16, 1, 100, 4, 80, 0.1, 0, None) != 0   # tokens != 192
+    assert lib.hm_layernorm(16, 16, 16, 16, 0, 4, 4098, 1e-6, None) != 0
+    assert lib.hm_hamer_workspace_bytes(None, 4) == 0
+
+
+def test_host_tensor_is_refused():
+    from hamer_yolo_amd import ops
+    with pytest.raises(L.HipLibraryError):
+        ops.layernorm(torch.zeros(4, 256), torch.ones(256), torch.zeros(256), 1e-5)
+
+
+def test_crop_box_helper_known_answers():
+    lib = L.load()
+    b = L.CropBox()
+    assert lib.hm_crop_box_from_bbox(250.0, 200.0, 256.0, 0, 256, C.byref(b)) == 0
+    assert (b.m0, b.m4, b.x0, b.y0, b.flip) == (1.0, 1.0, 122 * 1024 + 16, 72 * 1024 + 16, 0)
+    assert lib.hm_crop_box_from_bbox(100.0, 50.0, 512.0, 1, 256, C.byref(b)) == 0
+    assert (b.m0, b.m4, b.flip) == (2.0, 2.0, 1) and b.x0 == (100 - 256) * 1024 + 16
+    assert lib.hm_crop_box_from_bbox(1.0, 1.0, 0.0, 0, 256, C.byref(b)) != 0
+
+
+# ------------------------------------------------------------------ reference helper KATs
+def test_expand_to_aspect_ratio_and_crop_size_rule():
+    np.testing.assert_allclose(expand_to_aspect_ratio(np.array([300.0, 300.0]), [192, 256]), [300.0, 400.0])
+    np.testing.assert_allclose(expand_to_aspect_ratio(np.array([100.0, 400.0]), [192, 256]), [300.0, 400.0])
+    # square box of side s: S = 2.5 * s * 4/3 = 10 s / 3
+    cx, cy, S = crop_ref.bbox_to_center_size(100.0, 200.0, 160.0, 260.0)
+    assert (cx, cy) == (130.0, 230.0) and abs(S - 200.0) < 1e-9
+    np.testing.assert_allclose(crop_ref.expand_to_aspect_ratio(np.array([300.0, 300.0]), [192, 256]), [300.0, 400.0])
+
+
+def test_affine_matches_closed_form_and_oracle():
+    M = gen_trans_from_patch_cv(130.0, 230.0, 200.0, 200.0, 256, 256, 1.0, 0)
+    a = 256 / 200.0
+    np.testing.assert_allclose(M, [[a, 0, 128 - a * 130.0], [0, a, 128 - a * 230.0]], rtol=1e-12)
+    np.testing.assert_allclose(crop_ref.gen_trans_from_patch(130.0, 230.0, 200.0, 200.0, 256, 256), M, rtol=1e-9, atol=1e-9)
+    # float32 control points: a non-representable centre moves the matrix by ~1e-6, identically in both
+    M1 = gen_trans_from_patch_cv(130.123456789, 230.987654321, 123.456, 123.456, 256, 256)
+    M2 = crop_ref.gen_trans_from_patch(130.123456789, 230.987654321, 123.456, 123.456, 256, 256)
+    np.testing.assert_allclose(M1, M2, rtol=1e-9, atol=1e-7)
+
+
+def test_oracle_warp_identity_and_border():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8)
+    M = crop_ref.gen_trans_from_patch(200.0, 150.0, 256.0, 256.0, 256, 256)
+    out = crop_ref.warp_affine_u8(img, M, 256, 256)
+    assert np.array_equal(out, img[150 - 128:150 + 128, 200 - 128:200 + 128])
+    M = crop_ref.gen_trans_from_patch(10.0, 10.0, 256.0, 256.0, 256, 256)          # mostly outside: zeros
+    out = crop_ref.warp_affine_u8(img, M, 256, 256)
+    assert out[:117, :].max() == 0 and out[:, :117].max() == 0 and np.array_equal(out[118:, 118:], img[:138, :138])
+    # half-pixel shift: exact average of two neighbours with cv2's rounding (sum + 512) >> 10
+    M = crop_ref.gen_trans_from_patch(200.5, 150.0, 256.0, 256.0, 256, 256)
+    out = crop_ref.warp_affine_u8(img, M, 256, 256).astype(np.int64)
+    a = img[22:278, 72:328].astype(np.int64); b = img[22:278, 73:329].astype(np.int64)
+    assert np.array_equal(out, (512 * a + 512 * b + 512) >> 10)
+
+
+def test_cam_crop_to_full_known_answers():
+    cam = torch.tensor([[1.0, 0.0, 0.0]])
+    t = custom_cam_crop_to_full(cam, torch.tensor([[320.0, 240.0]]), torch.tensor([256.0]), torch.tensor([[640.0, 480.0]]),
+                                5000.0, 5000.0, 320.0, 240.0)
+    np.testing.assert_allclose(t.numpy(), [[0.0, 0.0, 2 * 5000.0 / 256.0]], rtol=1e-6)
+    t2 = cam_crop_to_full(cam, torch.tensor([[320.0, 240.0]]), torch.tensor([256.0]), torch.tensor([[640.0, 480.0]]), 5000.0)
+    np.testing.assert_allclose(t2.numpy(), t.numpy(), rtol=1e-6)
+    t3 = custom_cam_crop_to_full(cam, torch.tensor([[420.0, 240.0]]), torch.tensor([256.0]), torch.tensor([[640.0, 480.0]]),
+                                 1000.0, 500.0, 320.0, 240.0, depth_refine=2.0)
+    np.testing.assert_allclose(t3.numpy(), [[2 * 100.0 / 1000.0, 0.0, 2.0]], rtol=1e-5, atol=1e-7)
+
+
+def test_rodrigues_roundtrip():
+    from hamer_yolo_amd.infer import axis_angle_to_rotation_matrix_torch, matrix_to_axis_angle
+    aa = synth.uniform("aa", (64, 3), 1.7, seed=4)   # |aa| <= 2.95 < pi: the log map is unique
+    aa[0] = 0.0
+    aa[1] = torch.tensor([3.14159, 0.0, 0.0])
+    R = axis_angle_to_rotation_matrix_torch(aa).numpy()
+    back = matrix_to_axis_angle(R).reshape(-1, 3)
+    R2 = axis_angle_to_rotation_matrix_torch(torch.from_numpy(back)).numpy()
+    np.testing.assert_allclose(R2, R, atol=2e-6)
+    np.testing.assert_allclose(back[2:], aa[2:].numpy(), atol=2e-5)
+
+
+def test_cfg_node_surface():
+    cfg = get_config(None)
+    assert cfg.MODEL.IMAGE_SIZE == 256 and cfg.EXTRA.FOCAL_LENGTH == 5000 and cfg.MANO.NUM_HAND_JOINTS == 15
+    assert cfg.MODEL.get("BBOX_SHAPE", None) is None and "BBOX_SHAPE" not in cfg.MODEL
+    assert {k.lower() for k in dict(cfg.MANO)} >= {"model_path", "mean_params"}
+
+
+def test_hamer_refuses_cpu():
+    from hamer_yolo_amd.hamer.models.hamer import HAMER
+    from hamer_yolo_amd.hamer.models.mano_wrapper import MANO
+    m = HAMER(get_config(None), synth.hamer_state_dict(synth.tiny_config(), seed=0), MANO.synthetic(0), hamer_cfg=synth.tiny_config())
+    with pytest.raises(L.HipLibraryError):
+        m.to("cpu")
+    with pytest.raises(L.HipLibraryError):
+        m({"img": torch.zeros(1, 3, 256, 256)})
+
+
+def test_synth_is_deterministic_and_bf16_representable():
+    a = synth.uniform("x", (1000,), 0.3, seed=5)
+    b = synth.uniform("x", (1000,), 0.3, seed=5, chunk=77)
+    assert torch.equal(a, b) and float(a.abs().max()) <= 0.3 and a.std() > 0.15
+    sd = synth.hamer_state_dict(synth.tiny_config(), seed=2, bf16_representable=True)
+    w = sd["backbone.blocks.0.mlp.fc1.weight"]
+    assert torch.equal(w, w.bfloat16().float())
+    assert not torch.equal(sd["backbone.blocks.0.mlp.fc1.bias"], sd["backbone.blocks.0.mlp.fc1.bias"].bfloat16().float())
+
+
+# ------------------------------------------------------------------ shard path (gloo, world size 2)
+def test_shard_range():
+    assert [shard.shard_range(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]
+    assert [shard.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert shard.shard_range(3, 3, 4) == (3, 3)
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from hamer_yolo_amd import shard, synth
+rank, local, world = shard.init_distributed("gloo")
+cfg = synth.tiny_config()
+sd0 = synth.hamer_state_dict(cfg, seed=3) if rank == 0 else None
+import torch.distributed as dist
+meta = [{k: tuple(v.shape) for k, v in sd0.items()}] if rank == 0 else [None]
+dist.broadcast_object_list(meta, src=0)
+sd = shard.broadcast_state_dict(sd0, list(meta[0].keys()), meta[0], "cpu", src=0)
+ref = synth.hamer_state_dict(cfg, seed=3)
+assert all(torch.equal(sd[k], ref[k]) for k in ref), "broadcast weights differ"
+lo, hi = shard.shard_range(6, rank, world)
+B = hi - lo
+out = {"rotmats": torch.full((B, 16, 3, 3), float(rank)), "betas": torch.arange(lo, hi).float()[:, None].repeat(1, 10),
+       "pred_cam": torch.zeros(B, 3)}
+full = shard.gather_mano(shard.pack_mano(out), dst=0)
+if rank == 0:
+    assert full.shape == (6, 157)
+    assert torch.equal(full[:, 144], torch.arange(6).float()) and torch.equal(full[:, 0], torch.tensor([0., 0, 0, 1, 1, 1]))
+else:
+    assert full is None
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_broadcast_and_gather_on_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

@@ -179,6 +179,18 @@ def main():
                         rotmats=Rm.numpy(), verts=verts.numpy(), joints16_tips_manopth=jtr.numpy())
     print("manopth verts", verts.shape, float(verts.abs().max()))
 
+    # ---- container-only cross-check on the REAL MANO model (licensed arrays: nothing is saved)
+    real = os.path.join(REF, "rootnet/KeypointFusion/MANO/MANO_RIGHT.pkl")
+    if os.path.exists(real):
+        from hamer_yolo_amd.hamer.models.mano_wrapper import MANO
+        from oracle import hamer_ref as R
+        rp = MANO.from_pkl(real).params
+        v_ref, _ = manopth_forward(ml, rp, bt, aa)
+        v_or, _ = R.mano_forward(rp, bt, Rm)
+        err = float((v_ref - v_or).abs().max())
+        print(f"real MANO_RIGHT.pkl: oracle LBS vs manopth max |dv| = {err:.2e} m")
+        assert err < 5e-6
+
     if args.full:
         cfg = synth.HamerConfig()
         sd = synth.hamer_state_dict(cfg, seed=0, bf16_representable=True)
