@@ -19,6 +19,8 @@ EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
     "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
+    "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
+    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -68,6 +70,21 @@ class HamerWeights(C.Structure):
                 ("focal_length", C.c_float), ("image_size", C.c_float), ("dtype", C.c_int)]
 
 
+class ConvArgs(C.Structure):
+    _fields_ = [("X", vp), ("W", vp), ("Y", vp), ("bias", vp), ("zeros", vp)] + \
+               [(n, C.c_int) for n in ("N", "H", "W_in", "Cin", "Cout", "ksize", "stride", "ldx", "ldy", "Kpad", "act",
+                                       "out_f32", "dtype")]
+
+
+class YoloOp(C.Structure):
+    _fields_ = [("kind", C.c_int), ("pool_pad", C.c_int), ("conv", ConvArgs)]
+
+
+class LetterboxPlan(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("src_h", "src_w", "new_w", "new_h", "top", "left", "out_h", "out_w")] + \
+               [("gain", C.c_float), ("pad_x", C.c_float), ("pad_y", C.c_float)]
+
+
 class ProfRecord(C.Structure):
     _fields_ = [("kind", C.c_int), ("epilogue", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ms", C.c_float)]
 
@@ -108,6 +125,17 @@ def load() -> C.CDLL:
     lib.hm_hamer_workspace_bytes.argtypes = [C.POINTER(HamerWeights), i]
     lib.hm_hamer_workspace_bytes.restype = C.c_size_t
     lib.hm_hamer_forward.argtypes = [C.POINTER(HamerWeights), vp, i, C.POINTER(HamerOutputs), vp, C.c_size_t, vp]
+    lib.hm_conv2d_nhwc.argtypes = [C.POINTER(ConvArgs), vp]
+    lib.hm_maxpool_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, i, vp]
+    lib.hm_upsample2x_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]
+    lib.hm_letterbox_plan_make.argtypes = [i, i, i, i, C.POINTER(LetterboxPlan)]
+    lib.hm_letterbox_tables.argtypes = [C.POINTER(LetterboxPlan), C.POINTER(C.c_int32)]
+    lib.hm_letterbox.argtypes = [vp, C.POINTER(LetterboxPlan), vp, vp, i, vp, vp]
+    lib.hm_yolo_decode.argtypes = [vp, i, vp, i, i, i, i, f, C.POINTER(C.c_float), vp]
+    lib.hm_nms_workspace_bytes.argtypes = [i]
+    lib.hm_nms_workspace_bytes.restype = C.c_size_t
+    lib.hm_yolo_nms.argtypes = [vp, i, i, f, f, C.c_uint, i, i, C.POINTER(LetterboxPlan), vp, vp, vp, C.c_size_t, vp]
+    lib.hm_yolo_run.argtypes = [C.POINTER(YoloOp), i, vp]
     lib.hm_prof_begin.argtypes = [i]
     lib.hm_prof_collect.argtypes = [C.POINTER(ProfRecord), i]
     lib.hm_prof_end.argtypes = []
@@ -115,7 +143,7 @@ def load() -> C.CDLL:
         if not hasattr(lib, name):
             raise HipLibraryError(f"{LIB_PATH} does not export {name}")
         fn = getattr(lib, name)
-        if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes"):
+        if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes", "hm_nms_workspace_bytes"):
             fn.restype = i
     _lib = lib
     return lib

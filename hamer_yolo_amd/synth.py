@@ -250,3 +250,86 @@ def normalize_crops(u8: torch.Tensor) -> torch.Tensor:
     x = u8.permute(0, 3, 1, 2).to(torch.float32)
     # the reference does the arithmetic on float32 arrays with python-float (double) scalars
     return ((x - mean.float().view(1, 3, 1, 1)) / std.float().view(1, 3, 1, 1)).contiguous()
+
+
+# --------------------------------------------------------------------------- YOLOv7 weights
+# Per-layer weight-width factors that keep every convolution's pre-activation rms near 1 on a
+# seeded frame (a random-init CNN without them either explodes or dies within 100 layers).
+# Produced by tools/calibrate_yolo_synth.py and frozen here as constants.
+YOLO_CALIB: Dict[str, float] = {
+    "model.0.conv": 1.369, "model.1.conv": 1.653, "model.2.conv": 1.063, "model.3.conv": 1.058,
+    "model.4.conv": 1.231, "model.5.conv": 1.209, "model.6.conv": 1.178, "model.7.conv": 1.062,
+    "model.8.conv": 1.182, "model.9.conv": 1.136, "model.11.conv": 1.109, "model.13.conv": 0.864,
+    "model.14.conv": 0.991, "model.15.conv": 0.946, "model.17.conv": 1.227, "model.18.conv": 1.142,
+    "model.19.conv": 1.347, "model.20.conv": 1.105, "model.21.conv": 1.224, "model.22.conv": 1.008,
+    "model.24.conv": 1.239, "model.26.conv": 0.818, "model.27.conv": 1.264, "model.28.conv": 1.131,
+    "model.30.conv": 1.076, "model.31.conv": 1.133, "model.32.conv": 1.106, "model.33.conv": 1.001,
+    "model.34.conv": 1.163, "model.35.conv": 1.103, "model.37.conv": 1.157, "model.39.conv": 0.757,
+    "model.40.conv": 1.138, "model.41.conv": 1.078, "model.43.conv": 1.082, "model.44.conv": 1.082,
+    "model.45.conv": 1.135, "model.46.conv": 1.209, "model.47.conv": 1.181, "model.48.conv": 1.172,
+    "model.50.conv": 1.105, "model.51.cv1.conv": 1.111, "model.51.cv3.conv": 1.089, "model.51.cv4.conv": 1.134,
+    "model.51.cv5.conv": 0.372, "model.51.cv6.conv": 1.178, "model.51.cv2.conv": 1.082, "model.51.cv7.conv": 1.133,
+    "model.52.conv": 1.085, "model.54.conv": 1.178, "model.56.conv": 1.064, "model.57.conv": 1.027,
+    "model.58.conv": 1.055, "model.59.conv": 1.087, "model.60.conv": 1.064, "model.61.conv": 1.088,
+    "model.63.conv": 1.07, "model.64.conv": 1.042, "model.66.conv": 1.216, "model.68.conv": 1.14,
+    "model.69.conv": 1.094, "model.70.conv": 1.08, "model.71.conv": 1.166, "model.72.conv": 1.22,
+    "model.73.conv": 1.131, "model.75.conv": 1.041, "model.77.conv": 0.748, "model.78.conv": 0.987,
+    "model.79.conv": 1.103, "model.81.conv": 0.939, "model.82.conv": 0.991, "model.83.conv": 1.072,
+    "model.84.conv": 0.96, "model.85.conv": 0.964, "model.86.conv": 1.026, "model.88.conv": 1.04,
+    "model.90.conv": 0.68, "model.91.conv": 1.023, "model.92.conv": 1.093, "model.94.conv": 1.023,
+    "model.95.conv": 1.056, "model.96.conv": 1.234, "model.97.conv": 1.151, "model.98.conv": 1.066,
+    "model.99.conv": 1.188, "model.101.conv": 1.116, "model.102.rbr_reparam": 1.068, "model.103.rbr_reparam": 1.082,
+    "model.104.rbr_reparam": 1.152, "model.105.m.0": 2.945, "model.105.m.1": 3.242, "model.105.m.2": 2.914,
+}
+def yolo_state_dict(seed: int = 0, nc: int = 3, obj_bias: float = -4.0) -> Dict[str, torch.Tensor]:
+    """UNFUSED random-init YOLOv7 weights keyed like the reference ``Model(cfg/training/yolov7.yaml)``
+    state dict (Conv+BN pairs, RepConv branches, IDetect with ImplicitA/M).  Conv widths are
+    He-style so activations stay O(1) through the 105 layers; BatchNorm statistics are non-trivial.
+    ``obj_bias`` shifts the objectness logit so a small fraction of the 15120 candidates passes the
+    0.25 confidence threshold."""
+    from .yolo import arch
+    layers = arch.yolov7_layers()
+    specs = arch.conv_specs(layers, 3, nc)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def U(name, shape, hw, center=0.0):
+        sd[name] = uniform("yolo." + name, shape, hw, center, seed=seed)
+
+    def bn(prefix, c):
+        U(prefix + ".weight", (c,), 0.2, 1.0); U(prefix + ".bias", (c,), 0.1)
+        U(prefix + ".running_mean", (c,), 0.1); U(prefix + ".running_var", (c,), 0.3, 1.0)
+
+    for name, (co, ci, k, s) in specs.items():
+        hw = (6.0 / (ci * k * k)) ** 0.5 * YOLO_CALIB.get(name, 1.0)
+        if name.endswith(".conv"):
+            base = name[:-5]
+            U(name + ".weight", (co, ci, k, k), hw); bn(base + ".bn", co)
+        elif name.endswith(".rbr_reparam"):
+            base = name[:-len(".rbr_reparam")]
+            U(base + ".rbr_dense.0.weight", (co, ci, 3, 3), hw * 0.8); bn(base + ".rbr_dense.1", co)
+            U(base + ".rbr_1x1.0.weight", (co, ci, 1, 1), (6.0 / ci) ** 0.5 * 0.5 * YOLO_CALIB.get(name, 1.0)); bn(base + ".rbr_1x1.1", co)
+        else:
+            base, l = name.rsplit(".m.", 1)
+            U(name + ".weight", (co, ci, 1, 1), hw)
+            b = uniform("yolo." + name + ".bias", (co,), 0.5, seed=seed).view(3, -1)
+            b[:, 4] += obj_bias
+            sd[name + ".bias"] = b.reshape(-1)
+            U(f"{base}.ia.{l}.implicit", (1, ci, 1, 1), 0.02)
+            U(f"{base}.im.{l}.implicit", (1, co, 1, 1), 0.02, 1.0)
+    return sd
+
+
+def frame_u8(h: int = 1080, w: int = 1920, seed: int = 0, smooth: int = 8) -> torch.Tensor:
+    """(h, w, 3) uint8 BGR synthetic frame: seeded noise on a coarse grid, bilinearly upsampled, plus
+    fine noise -- integer arithmetic only, so it is identical on every machine (pure white noise
+    would be a degenerate input for a resize)."""
+    s = smooth
+    gh, gw = h // s + 2, w // s + 2
+    coarse = (_hash_u32(torch.arange(gh * gw * 3, dtype=torch.int64), name_seed("frame.coarse", seed)) >> 24).reshape(gh, gw, 3)
+    ys, xs = torch.arange(h, dtype=torch.int64), torch.arange(w, dtype=torch.int64)
+    y0, fy, x0, fx = ys // s, (ys % s)[:, None, None], xs // s, (xs % s)[None, :, None]
+    c00, c01 = coarse[y0][:, x0], coarse[y0][:, x0 + 1]
+    c10, c11 = coarse[y0 + 1][:, x0], coarse[y0 + 1][:, x0 + 1]
+    img = (c00 * (s - fy) * (s - fx) + c01 * (s - fy) * fx + c10 * fy * (s - fx) + c11 * fy * fx) // (s * s)
+    fine = (_hash_u32(torch.arange(h * w * 3, dtype=torch.int64), name_seed("frame.fine", seed)) >> 27).reshape(h, w, 3) - 16
+    return (img + fine).clamp(0, 255).to(torch.uint8).contiguous()

@@ -1,0 +1,215 @@
+"""YoloEngine: device-resident fused YOLOv7 weights + a planned op list per input size.
+
+Load time (host, once): BN / RepConv / implicit folding (fuse.py), weights re-laid out as
+[Cout][ky][kx][Cin] 16-bit rows padded to a multiple of 64 (the implicit-GEMM K axis).
+Plan time (host, once per letterboxed size): every tensor gets a home in an NHWC arena; a tensor
+that feeds a Concat lives directly in a channel slice of the concat's buffer, so Concat costs
+nothing (reference: Model.forward_once, yolo.py:609-639, copies on every torch.cat).
+Run time: hm_letterbox -> hm_yolo_run (one enqueue for ~110 kernels) -> 3 x hm_yolo_decode -> hm_yolo_nms.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import lib as L
+from . import arch, fuse
+
+
+def _kpad(k: int) -> int:
+    return (k + 63) // 64 * 64
+
+
+class YoloEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], nc: int = 3, device="cuda", dtype=torch.float16,
+                 new_shape: int = 640, stride: int = 32):
+        if not torch.cuda.is_available():
+            raise L.HipLibraryError("YoloEngine needs an MI355X (HIP device); there is no CPU fallback")
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.dt = L.HM_DTYPE_BF16 if dtype == torch.bfloat16 else L.HM_DTYPE_F16
+        self.nc, self.no = nc, nc + 5
+        self.new_shape, self.stride = new_shape, stride
+        self.layers = arch.yolov7_layers()
+        self.specs = arch.conv_specs(self.layers, 3, nc)
+        fused = fuse.fuse_state_dict(state_dict, self.specs)
+        self.w: Dict[str, Tuple[torch.Tensor, torch.Tensor, int, int, int, int]] = {}
+        for name, (co, ci, k, s) in self.specs.items():
+            w, b = fused[name]
+            cin = 8 if ci == 3 else ci                      # the image is stored with 8 channels (3 real)
+            wk = torch.zeros(co, k, k, cin, dtype=torch.float32)
+            wk[:, :, :, :ci] = w.permute(0, 2, 3, 1)
+            flat = torch.zeros(co, _kpad(k * k * cin), dtype=torch.float32)
+            flat[:, :k * k * cin] = wk.reshape(co, -1)
+            self.w[name] = (flat.to(self.device, dtype).contiguous(), b.to(self.device, torch.float32).contiguous(), cin, k, s, co)
+        self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
+        self.names = ['0', '1', '2']                         # class names live in the checkpoint (detector.py:157)
+        self._plans: Dict[Tuple[int, int], dict] = {}
+
+    # ------------------------------------------------------------------ planning
+    def _plan(self, H: int, W: int) -> dict:
+        key = (H, W)
+        if key in self._plans:
+            return self._plans[key]
+        lib = self.lib
+        lp = L.LetterboxPlan()
+        L.check(lib.hm_letterbox_plan_make(H, W, self.new_shape, self.stride, C.byref(lp)), "hm_letterbox_plan_make")
+        tab = (C.c_int32 * (3 * lp.new_w + 3 * lp.new_h))()
+        L.check(lib.hm_letterbox_tables(C.byref(lp), tab), "hm_letterbox_tables")
+        tab_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.int32).clone().to(self.device)
+
+        layers = arch.resolve(self.layers)
+        ch = arch.channels(self.layers, 3, self.nc)
+        # spatial size per layer
+        hw: List[Tuple[int, int]] = []
+        for i, (srcs, kind, args) in enumerate(layers):
+            h, w = (lp.out_h, lp.out_w) if srcs[0] < 0 else hw[srcs[0]]
+            if kind == "conv" and args[2] == 2:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1      # k3 s2 p1
+            elif kind == "mp":
+                h, w = h // 2, w // 2
+            elif kind == "up":
+                h, w = 2 * h, 2 * w
+            hw.append((h, w))
+        # homes: (buffer id, channel offset, ld); concat members live inside the concat buffer
+        home: Dict[int, Tuple[int, int, int]] = {}
+        sizes: Dict[int, int] = {}                          # buffer id -> elements
+        for j, (srcs, kind, _) in enumerate(layers):
+            if kind == "concat":
+                off = 0
+                for s in srcs:
+                    assert s not in home, "a tensor may join one concat only"
+                    home[s] = (j, off, ch[j])
+                    off += ch[s]
+                sizes[j] = hw[j][0] * hw[j][1] * ch[j]
+        for i, (srcs, kind, _) in enumerate(layers):
+            if kind == "concat":
+                home.setdefault(i, (i, 0, ch[i]))
+            elif kind != "detect" and i not in home:
+                home[i] = (i, 0, ch[i])
+                sizes[i] = hw[i][0] * hw[i][1] * ch[i]
+        # extra buffers: image (8 ch), SPPCSPC internals, detect raw maps (f32)
+        IMG = -1
+        sizes[IMG] = lp.out_h * lp.out_w * 8
+        home[IMG] = (IMG, 0, 8)
+        spp_i = next(i for i, (_, kind, _) in enumerate(layers) if kind == "sppcspc")
+        c_ = layers[spp_i][2][0]
+        sh, sw = hw[spp_i]
+        spp = {"t1": 1000, "t3": 1001, "cat4": 1002, "t5": 1003, "cat2": 1004}
+        for nm, cc in (("t1", c_), ("t3", c_), ("cat4", 4 * c_), ("t5", c_), ("cat2", 2 * c_)):
+            sizes[spp[nm]] = sh * sw * cc
+        offs, total = {}, 0
+        for b, n in sizes.items():
+            offs[b] = total
+            total += (n * 2 + 255) // 256 * 256
+        arena = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        base = arena.data_ptr()
+        esz = 2
+
+        def addr(buf, ch_off=0):
+            return base + offs[buf] + ch_off * esz
+
+        def loc(i):
+            b, o, ld = home[i]
+            return addr(b, o), ld
+
+        ops: List[L.YoloOp] = []
+
+        def conv(name, xptr, ldx, h, w, yptr, ldy, act=1, out_f32=0):
+            wt, bs, cin, k, s, co = self.w[name]
+            a = L.ConvArgs(xptr, wt.data_ptr(), yptr, bs.data_ptr(), self.zeros.data_ptr(), 1, h, w, cin, co, k, s, ldx, ldy,
+                           wt.shape[1], act, out_f32, self.dt)
+            ops.append(L.YoloOp(0, 0, a))
+
+        def pool(xptr, ldx, h, w, c, yptr, ldy, k, s, pad):
+            a = L.ConvArgs(xptr, None, yptr, None, None, 1, h, w, c, c, k, s, ldx, ldy, 0, 0, 0, self.dt)
+            ops.append(L.YoloOp(1, pad, a))
+
+        raws = []
+        for i, (srcs, kind, args) in enumerate(layers):
+            if kind == "concat":
+                continue
+            s0 = srcs[0] if srcs[0] >= 0 else IMG
+            xptr, ldx = loc(s0)
+            h, w = (lp.out_h, lp.out_w) if s0 == IMG else hw[s0]
+            if kind == "conv":
+                yptr, ldy = loc(i)
+                conv(f"model.{i}.conv", xptr, ldx, h, w, yptr, ldy)
+            elif kind == "repconv":
+                yptr, ldy = loc(i)
+                conv(f"model.{i}.rbr_reparam", xptr, ldx, h, w, yptr, ldy)
+            elif kind == "mp":
+                yptr, ldy = loc(i)
+                pool(xptr, ldx, h, w, ch[s0], yptr, ldy, 2, 2, 0)
+            elif kind == "up":
+                yptr, ldy = loc(i)
+                a = L.ConvArgs(xptr, None, yptr, None, None, 1, h, w, ch[s0], ch[s0], 1, 1, ldx, ldy, 0, 0, 0, self.dt)
+                ops.append(L.YoloOp(2, 0, a))
+            elif kind == "sppcspc":                          # common.py:279-284
+                p = f"model.{i}."
+                conv(p + "cv1.conv", xptr, ldx, h, w, addr(spp["t1"]), c_)
+                conv(p + "cv3.conv", addr(spp["t1"]), c_, h, w, addr(spp["t3"]), c_)
+                conv(p + "cv4.conv", addr(spp["t3"]), c_, h, w, addr(spp["cat4"], 0), 4 * c_)          # x1
+                for step in range(3):                        # maxpool 5, 9 = 5o5, 13 = 5o5o5 (stride 1, -inf padding)
+                    pool(addr(spp["cat4"], step * c_), 4 * c_, h, w, c_, addr(spp["cat4"], (step + 1) * c_), 4 * c_, 5, 1, 2)
+                conv(p + "cv5.conv", addr(spp["cat4"]), 4 * c_, h, w, addr(spp["t5"]), c_)
+                conv(p + "cv6.conv", addr(spp["t5"]), c_, h, w, addr(spp["cat2"], 0), 2 * c_)           # y1
+                conv(p + "cv2.conv", xptr, ldx, h, w, addr(spp["cat2"], c_), 2 * c_)                     # y2
+                yptr, ldy = loc(i)
+                conv(p + "cv7.conv", addr(spp["cat2"]), 2 * c_, h, w, yptr, ldy)
+            elif kind == "detect":
+                for l, s in enumerate(srcs):
+                    xp, ldxx = loc(s)
+                    hh, ww = hw[s]
+                    raw = torch.empty(hh * ww, 3 * self.no, dtype=torch.float32, device=self.device)
+                    raws.append((raw, hh, ww))
+                    conv(f"model.{i}.m.{l}", xp, ldxx, hh, ww, raw.data_ptr(), 3 * self.no, act=0, out_f32=1)
+        op_arr = (L.YoloOp * len(ops))(*ops)
+        n_pred = sum(3 * hh * ww for _, hh, ww in raws)
+        plan = {
+            "lp": lp, "tab": tab_dev, "arena": arena, "img_ptr": addr(IMG), "ops": op_arr, "n_ops": len(ops), "raws": raws,
+            "pred": torch.empty(n_pred, self.no, dtype=torch.float32, device=self.device),
+            "dets": torch.zeros(300, 6, dtype=torch.float32, device=self.device),
+            "count": torch.zeros(1, dtype=torch.int32, device=self.device),
+            "nms_ws": torch.empty(self.lib.hm_nms_workspace_bytes(n_pred), dtype=torch.uint8, device=self.device),
+            "u8": torch.empty(3, lp.out_h, lp.out_w, dtype=torch.uint8, device=self.device),
+        }
+        self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ run
+    def letterbox(self, frame: torch.Tensor, want_u8: bool = False):
+        H, W, _ = frame.shape
+        p = self._plan(H, W)
+        L.check(self.lib.hm_letterbox(frame.data_ptr(), C.byref(p["lp"]), p["tab"].data_ptr(), p["img_ptr"], self.dt,
+                                      p["u8"].data_ptr() if want_u8 else None, L.current_stream()), "hm_letterbox")
+        return p
+
+    def forward(self, frame: torch.Tensor, want_u8: bool = False) -> dict:
+        """frame: (H, W, 3) uint8 BGR on the device -> plan dict with ``pred`` (n, 5+nc) filled."""
+        if not frame.is_cuda or frame.dtype != torch.uint8:
+            raise L.HipLibraryError("YoloEngine.forward takes a uint8 device frame")
+        p = self.letterbox(frame.contiguous(), want_u8)
+        st = L.current_stream()
+        L.check(self.lib.hm_yolo_run(p["ops"], p["n_ops"], st), "hm_yolo_run")
+        row0 = 0
+        for l, (raw, hh, ww) in enumerate(p["raws"]):
+            anc = (C.c_float * 6)(*[float(v) for v in arch.ANCHORS[l]])
+            L.check(self.lib.hm_yolo_decode(raw.data_ptr(), 3 * self.no, p["pred"].data_ptr(), row0, hh, ww, self.nc,
+                                            float(arch.STRIDES[l]), anc, st), "hm_yolo_decode")
+            row0 += 3 * hh * ww
+        return p
+
+    def nms(self, p: dict, conf_thres: float, iou_thres: float, classes: Optional[List[int]], agnostic: bool,
+            scale: bool = True, max_det: int = 300) -> torch.Tensor:
+        mask = 0xFFFFFFFF if classes is None else sum(1 << int(c) for c in classes)
+        n = p["pred"].shape[0]
+        L.check(self.lib.hm_yolo_nms(p["pred"].data_ptr(), n, self.nc, conf_thres, iou_thres, mask, int(bool(agnostic)), max_det,
+                                     C.byref(p["lp"]) if scale else None, p["dets"].data_ptr(), p["count"].data_ptr(),
+                                     p["nms_ws"].data_ptr(), p["nms_ws"].numel(), L.current_stream()), "hm_yolo_nms")
+        k = int(p["count"].item())                            # the one host sync of the detector (the box list is host data)
+        return p["dets"][:k].clone()

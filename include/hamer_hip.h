@@ -182,6 +182,76 @@ size_t hm_hamer_workspace_bytes(const hm_hamer_weights* w, int B);
 int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- YOLOv7 detector path
+ * Activations are NHWC 16-bit tensors addressed as (base pointer, pixel stride in elements): a
+ * producer can write straight into a channel slice of a concat buffer (Concat, common.py:60-66,
+ * costs nothing), a consumer can read a slice the same way. */
+typedef struct hm_conv_args {
+  const void* X;      /* [N][H][W_in][ldx] 16-bit, pointer already offset to the first input channel   */
+  const void* W;      /* [Cout][Kpad] 16-bit, K order (ky, kx, ci), zero padded to Kpad (% 64 == 0)   */
+  void* Y;            /* [N][Hout][Wout][ldy] 16-bit (or f32 when out_f32), offset to the channel slice */
+  const float* bias;  /* [Cout]                                                                        */
+  const void* zeros;  /* >= 16 zero bytes on the device: source of padding taps                        */
+  int N, H, W_in, Cin, Cout, ksize, stride, ldx, ldy, Kpad;
+  int act;            /* 1: SiLU (Conv.fuseforward, common.py:114)                                     */
+  int out_f32;        /* 1: f32 output, no activation (detect head, yolo.py:151)                       */
+  int dtype;
+} hm_conv_args;
+
+/* Conv2d(k in {1,3}, stride in {1,2}, pad k/2) + bias (+ SiLU) as an implicit GEMM on MFMA.
+ * Cin must be a power of two >= 8 (the 3-channel image is stored with 8 channels). */
+int hm_conv2d_nhwc(const hm_conv_args* args, void* stream);
+
+/* nn.MaxPool2d(k, stride, pad) on NHWC 16-bit (MP common.py:34-40: k=2,s=2; SPPCSPC common.py:275:
+ * k=5/9/13, s=1, pad k/2 -- the 9 and 13 windows are cascades of the 5 window). C % 8 == 0. */
+int hm_maxpool_nhwc(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int k, int stride, int pad,
+                    int dtype, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode='nearest') on NHWC 16-bit (yolov7.yaml:78,:92). C % 8 == 0. */
+int hm_upsample2x_nhwc(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);
+
+/* letterbox (utils/datasets.py:999-1029, auto=True) + LoadImage.process_img (:137-141) + /255
+ * (detector.py:121-125).  The plan is host-side scalar work; the resize follows cv2's 8-bit
+ * INTER_LINEAR fixed-point algorithm (11-bit coefficients). */
+typedef struct hm_letterbox_plan {
+  int src_h, src_w;     /* frame size                                  */
+  int new_w, new_h;     /* resized (unpadded) size                      */
+  int top, left;        /* padding before the resized image             */
+  int out_h, out_w;     /* network input size (multiples of the stride) */
+  float gain, pad_x, pad_y; /* scale_coords inputs (general.py:323-331) */
+} hm_letterbox_plan;
+int hm_letterbox_plan_make(int H, int W, int new_shape, int stride, hm_letterbox_plan* plan);      /* host */
+/* host: tab[0:new_w]=x0, [new_w:2new_w]=ax0, [2new_w:3new_w]=ax1, then y0, ay0, ay1 (3*new_h)     */
+int hm_letterbox_tables(const hm_letterbox_plan* plan, int32_t* tab_host);
+/* frame [H][W][3] u8 BGR -> x8 [out_h][out_w][8] 16-bit RGB/255 (+5 zero channels), and optionally
+ * u8_chw [3][out_h][out_w] RGB (the reference's uint8 network input, for parity checks). */
+int hm_letterbox(const uint8_t* frame, const hm_letterbox_plan* plan, const int32_t* tab_dev, void* x8, int dtype,
+                 uint8_t* u8_chw, void* stream);
+
+/* Detect decode (IDetect.fuseforward, yolo.py:148-184): raw [ny*nx][3*(5+nc)] f32 of one level ->
+ * rows [row0 + a*ny*nx + y*nx + x][5+nc] of pred: sigmoid, xy = (2s-0.5+grid)*stride, wh = (2s)^2*anchor. */
+int hm_yolo_decode(const float* raw, int ldraw, float* pred, int row0, int ny, int nx, int nc, float stride,
+                   const float* anchors6_host, void* stream);
+
+/* non_max_suppression (utils/general.py:611-703, best-class branch) + scale_coords/clip/round
+ * (general.py:323-344, detector.py:142).  pred [n][5+nc] f32.  class_mask: bit c set = class c kept.
+ * Workspace: hm_nms_workspace_bytes(n).  dets [max_det][6] f32 = x1,y1,x2,y2,conf,cls (score order),
+ * count[0] = number of rows.  When plan != NULL boxes are mapped to frame pixels and rounded. */
+size_t hm_nms_workspace_bytes(int n);
+int hm_yolo_nms(const float* pred, int n, int nc, float conf_thres, float iou_thres, unsigned class_mask, int agnostic,
+                int max_det, const hm_letterbox_plan* plan, float* dets, int* count, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* One enqueue for a whole planned graph (Model.forward_once, yolo.py:609-639): the host planner
+ * (hamer_yolo_amd/yolo/engine.py) turns the layer list into this op array once per input size. */
+enum { HM_OP_CONV = 0, HM_OP_MAXPOOL = 1, HM_OP_UPSAMPLE2X = 2 };
+typedef struct hm_yolo_op {
+  int kind;
+  int pool_pad;       /* HM_OP_MAXPOOL: padding; ksize/stride/N/H/W_in/Cin(=C)/X/Y/ldx/ldy/dtype come from conv */
+  hm_conv_args conv;
+} hm_yolo_op;
+int hm_yolo_run(const hm_yolo_op* ops_host, int n_ops, void* stream);
+
 /* Optional per-launch timing (HIP events on the launch stream); kinds below. */
 enum { HM_K_GEMM = 0, HM_K_LAYERNORM = 1, HM_K_ATTENTION = 2, HM_K_IM2COL = 3, HM_K_LINEAR_F32 = 4,
        HM_K_CROSS_ATTN = 5, HM_K_MANO = 6, HM_K_CROP = 7, HM_K_CONV = 8, HM_K_OTHER = 9 };

@@ -1,0 +1,186 @@
+"""GPU parity of the detector path through the C ABI: implicit-GEMM convolution, pooling,
+letterbox (byte-exact), decode, NMS (index-exact) and the whole Detector.detect."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hamer_yolo_amd import lib as L
+from hamer_yolo_amd import synth
+from hamer_yolo_amd.yolo import arch, fuse
+from hamer_yolo_amd.yolo.detector import Detector
+from hamer_yolo_amd.yolo.engine import YoloEngine
+from oracle import yolo_ref
+
+DEV = "cuda"
+
+
+def _conv_gpu(x_nchw, w, b, k, s, act, dt, out_f32=False, ld_extra=0, y_extra=0):
+    """Run hm_conv2d_nhwc on an NHWC copy (optionally inside wider buffers to exercise strides)."""
+    lib = L.load()
+    N, Ci, H, W = x_nchw.shape
+    Co = w.shape[0]
+    cin = 8 if Ci < 8 else Ci
+    xb = torch.zeros(N, H, W, cin + ld_extra, dtype=dt)
+    xb[..., ld_extra:ld_extra + Ci] = x_nchw.permute(0, 2, 3, 1).to(dt)
+    wk = torch.zeros(Co, k, k, cin)
+    wk[..., :Ci] = w.permute(0, 2, 3, 1)
+    kp = (k * k * cin + 63) // 64 * 64
+    wf = torch.zeros(Co, kp)
+    wf[:, :k * k * cin] = wk.reshape(Co, -1)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    xd, wd, bd = xb.to(DEV), wf.to(dt).to(DEV), b.float().to(DEV)
+    yd = torch.zeros(N, Ho, Wo, Co + y_extra, dtype=torch.float32 if out_f32 else dt, device=DEV)
+    zeros = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    esz = 2
+    a = L.ConvArgs(xd.data_ptr() + ld_extra * esz, wd.data_ptr(), yd.data_ptr() + y_extra * (4 if out_f32 else 2), bd.data_ptr(),
+                   zeros.data_ptr(), N, H, W, cin, Co, k, s, cin + ld_extra, Co + y_extra, kp, int(act), int(out_f32),
+                   L.HM_DTYPE_BF16 if dt == torch.bfloat16 else L.HM_DTYPE_F16)
+    L.check(lib.hm_conv2d_nhwc(C.byref(a), L.current_stream()), "hm_conv2d_nhwc")
+    torch.cuda.synchronize()
+    y = yd.cpu().float()
+    assert (y[..., :y_extra] == 0).all()                      # the neighbouring channel slice is untouched
+    return y[..., y_extra:].permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Co,k,s,H,W", [(3, 32, 3, 1, 40, 72), (32, 64, 3, 2, 38, 70), (64, 64, 1, 1, 24, 40), (128, 256, 3, 1, 12, 20),
+                                            (256, 24, 1, 1, 12, 20), (64, 128, 3, 2, 31, 33), (512, 512, 3, 1, 6, 10)])
+def test_conv2d_nhwc_vs_torch(Ci, Co, k, s, H, W, dt):
+    x = synth.uniform("cx", (2, Ci, H, W), 1.0, seed=Ci).to(dt).float()
+    w = synth.uniform("cw", (Co, Ci, k, k), (3.0 / (Ci * k * k)) ** 0.5, seed=Co).to(dt).float()
+    b = synth.uniform("cb", (Co,), 0.3, seed=k)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=k // 2).float()
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    y = _conv_gpu(x, w, b, k, s, act=True, dt=dt, ld_extra=8 if Ci >= 8 else 0, y_extra=8)
+    np.testing.assert_allclose(y.numpy(), F.silu(ref).numpy(), atol=2e-3, rtol=2 * ulp)
+    y = _conv_gpu(x, w, b, k, s, act=False, dt=dt, out_f32=True)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=2e-4, rtol=1e-5)
+
+
+def test_conv_exact_integer_data():
+    x = (torch.arange(2 * 16 * 9 * 11).reshape(2, 16, 9, 11) % 5 - 2).float()
+    w = ((torch.arange(32 * 16 * 9).reshape(32, 16, 3, 3) * 7 + torch.arange(32)[:, None, None, None]) % 3 - 1).float()
+    ref = F.conv2d(x, w, torch.zeros(32), stride=1, padding=1)
+    y = _conv_gpu(x, w, torch.zeros(32), 3, 1, act=False, dt=torch.float16, out_f32=True)
+    assert torch.equal(y, ref)
+
+
+def test_maxpool_and_upsample():
+    lib = L.load()
+    x = synth.uniform("px", (1, 64, 12, 20), 2.0, seed=1).half()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = torch.empty(1, 6, 10, 64, dtype=torch.float16, device=DEV)
+    L.check(lib.hm_maxpool_nhwc(xd.data_ptr(), 64, y.data_ptr(), 64, 1, 12, 20, 64, 2, 2, 0, L.HM_DTYPE_F16, L.current_stream()))
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), F.max_pool2d(x.float(), 2, 2).half())
+    # SPP cascade: 5, 9 = 5o5, 13 = 5o5o5 written into channel slices of one buffer
+    cat = torch.zeros(1, 12, 20, 256, dtype=torch.float16, device=DEV)
+    cat[..., :64] = xd
+    for step in range(3):
+        L.check(lib.hm_maxpool_nhwc(cat.data_ptr() + step * 128, 256, cat.data_ptr() + (step + 1) * 128, 256, 1, 12, 20, 64, 5, 1, 2,
+                                    L.HM_DTYPE_F16, L.current_stream()))
+    ref = torch.cat([x.float()] + [F.max_pool2d(x.float(), k, 1, k // 2) for k in (5, 9, 13)], 1)
+    assert torch.equal(cat.cpu().permute(0, 3, 1, 2).float(), ref)
+    up = torch.empty(1, 24, 40, 64, dtype=torch.float16, device=DEV)
+    L.check(lib.hm_upsample2x_nhwc(xd.data_ptr(), 64, up.data_ptr(), 64, 1, 12, 20, 64, L.HM_DTYPE_F16, L.current_stream()))
+    assert torch.equal(up.cpu().permute(0, 3, 1, 2).float(), F.interpolate(x.float(), scale_factor=2, mode="nearest"))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    return YoloEngine(synth.yolo_state_dict(seed=0, nc=3), nc=3, device=DEV)
+
+
+@pytest.mark.parametrize("hw", [(1080, 1920), (565, 848), (384, 640), (700, 500)])
+def test_letterbox_bit_exact(engine, hw):
+    frame = synth.frame_u8(hw[0], hw[1], seed=hw[0])
+    p = engine.letterbox(frame.to(DEV), want_u8=True)
+    torch.cuda.synchronize()
+    ref, g = yolo_ref.letterbox(frame.numpy())
+    got = p["u8"].cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    lp = p["lp"]
+    x8 = torch.empty(lp.out_h * lp.out_w * 8, dtype=torch.float16, device=DEV)
+    # the network input tensor: RGB/255 in the first 3 of 8 channels
+    img = torch.frombuffer(bytearray(8), dtype=torch.uint8)   # placeholder to keep flake quiet
+    arena = p["arena"]
+    off = p["img_ptr"] - arena.data_ptr()
+    x8 = arena[off:off + lp.out_h * lp.out_w * 16].view(torch.float16).reshape(lp.out_h, lp.out_w, 8).cpu().float()
+    np.testing.assert_allclose(x8[..., :3].permute(2, 0, 1).numpy(), ref.astype(np.float32) / 255.0, atol=5e-4)
+    assert (x8[..., 3:] == 0).all()
+
+
+def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, "yolo_forward.npz"))
+    frame = synth.frame_u8(384, 640, seed=int(g["frame_seed"]))          # already network-sized: letterbox is the identity
+    p = engine.forward(frame.to(DEV))
+    torch.cuda.synchronize()
+    pred = p["pred"].cpu()
+    assert pred.shape == (15120, 8) and torch.isfinite(pred).all()
+    ref_rows = torch.from_numpy(g["pred_rows"])
+    got = pred[::9]
+    # fp16 activations through 105 layers vs the fp32 CPU reference: boxes within 2 % of their size scale, scores within 0.02
+    assert float((got[:, 4:] - ref_rows[:, 4:]).abs().max()) < 2e-2
+    size = ref_rows[:, 2:4].abs().mean(1, keepdim=True).clamp_min(8.0)
+    assert float(((got[:, :4] - ref_rows[:, :4]).abs() / size).max()) < 3e-2
+    np.testing.assert_allclose(pred.double().sum(0).numpy(), g["pred_sum"], rtol=5e-3)
+
+
+def test_nms_exact_on_reference_prediction(engine, golden_dir):
+    """Feed the reference's own prediction rows to the HIP NMS: the kept rows must equal the reference's output."""
+    g = np.load(os.path.join(golden_dir, "yolo_forward.npz"))
+    p = engine._plan(384, 640)
+    cand = torch.from_numpy(g["pred_cand"])
+    pred = torch.zeros(15120, 8)
+    perm = (synth._hash_u32(torch.arange(15120, dtype=torch.int64), 5) % 15120).unique()[:len(cand)].sort().values
+    pred[perm] = cand                                                     # scattered, original order preserved
+    p["pred"].copy_(pred.to(DEV))
+    det = engine.nms(p, 0.25, 0.35, [0, 1, 2], True, scale=False).cpu()
+    assert torch.equal(det, torch.from_numpy(g["dets"]))
+    det1 = engine.nms(p, 0.25, 0.35, [1], False, scale=False).cpu()
+    assert torch.equal(det1, torch.from_numpy(g["dets_cls1"]))
+    # scaled + rounded variant vs the oracle's scale_coords on a 1080p plan
+    p2 = engine._plan(1080, 1920)
+    p2["pred"].copy_(pred.to(DEV))
+    det2 = engine.nms(p2, 0.25, 0.35, [0, 1, 2], True, scale=True).cpu()
+    ref = torch.from_numpy(g["dets"]).clone()
+    ref[:, :4] = yolo_ref.scale_coords((384, 640), ref[:, :4], (1080, 1920, 3)).round()
+    assert torch.equal(det2, ref)
+    # empty input
+    p["pred"].zero_()
+    assert engine.nms(p, 0.25, 0.35, None, True).shape == (0, 6)
+
+
+def test_detector_detect_vs_oracle():
+    class Opt:
+        weights = "synthetic:0"; imgsz = 640; augment = True; conf_thres = 0.25; iou_thres = 0.35
+        classes = [0, 1, 2]; agnostic_nms = True; device = "cuda"; save_path = "./output"
+    det = Detector(Opt)
+    frame = synth.frame_u8(540, 960, seed=11)
+    pred, dets_list = det.detect(frame.numpy())
+    layers = arch.yolov7_layers()
+    fused = fuse.fuse_state_dict(synth.yolo_state_dict(seed=0, nc=3), arch.conv_specs(layers, 3, 3))
+    with torch.no_grad():
+        ref_dets, ref_list, _ = yolo_ref.detect(layers, fused, frame.numpy(), 3, arch.ANCHORS)
+    got, ref = pred[0].cpu(), ref_dets[0]
+    assert len(dets_list) == 1 and len(dets_list[0]) == len(got) and got.shape[1] == 6
+    assert all(lbl in ("left", "right") for lbl, _ in dets_list[0])
+    assert [lbl for lbl, _ in dets_list[0]] == ['right' if c == 1 else 'left' for c in got[:, 5].tolist()]
+    assert abs(len(got) - len(ref)) <= max(3, len(ref) // 20)
+    # match every reference box to a detection of the same class (fp16 network vs fp32 oracle)
+    def iou(a, b):
+        lt, rb = torch.max(a[:, None, :2], b[None, :, :2]), torch.min(a[:, None, 2:4], b[None, :, 2:4])
+        inter = (rb - lt).clamp(min=0).prod(-1)
+        area = lambda t: (t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])
+        return inter / (area(a)[:, None] + area(b)[None] - inter + 1e-9)
+    m = iou(ref, got)
+    same = ref[:, 5:6] == got[None, :, 5]
+    best, idx = (m * same).max(1)
+    assert float((best > 0.9).float().mean()) > 0.93
+    ok = best > 0.9
+    assert float((ref[ok, 4] - got[idx[ok], 4]).abs().max()) < 3e-2
