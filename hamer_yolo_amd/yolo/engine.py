@@ -177,9 +177,18 @@ class YoloEngine:
             "count": torch.zeros(1, dtype=torch.int32, device=self.device),
             "nms_ws": torch.empty(self.lib.hm_nms_workspace_bytes(n_pred), dtype=torch.uint8, device=self.device),
             "u8": torch.empty(3, lp.out_h, lp.out_w, dtype=torch.uint8, device=self.device),
+            "home": home, "hw": hw, "ch": ch, "offs": offs,
         }
         self._plans[key] = plan
         return plan
+
+    def layer_output(self, p: dict, i: int) -> torch.Tensor:
+        """(C, H, W) fp32 copy of layer i's output inside the arena (debug / tests)."""
+        b, o, ld = p["home"][i]
+        h, w = p["hw"][i]
+        start = p["offs"][b]
+        buf = p["arena"][start:start + h * w * ld * 2].view(self.dtype).reshape(h, w, ld)
+        return buf[:, :, o:o + p["ch"][i]].permute(2, 0, 1).float().cpu()
 
     # ------------------------------------------------------------------ run
     def letterbox(self, frame: torch.Tensor, want_u8: bool = False):
