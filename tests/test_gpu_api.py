@@ -1,0 +1,110 @@
+"""GPU: the reference-shaped Python API end to end (hamer_inference.estimate_from_rgb, .npy records)
+against the oracle pipeline (crop_ref -> hamer_ref -> the reference's camera formulas)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hamer_yolo_amd import synth
+from hamer_yolo_amd.infer import (axis_angle_to_rotation_matrix_torch, hamer_inference, hand_record,
+                                  reconstruct_and_save_obj_with_wrapper)
+from oracle import crop_ref
+from oracle import hamer_ref as R
+
+
+class _Cfg:
+    ckpt_path = "synthetic:0"
+    model_cfg = None
+    use_onnx = False
+    onnx_path = None
+
+
+@pytest.fixture(scope="module")
+def hi():
+    return hamer_inference(_Cfg)
+
+
+def _oracle_pipeline(frame, dets, k_real):
+    cfg = synth.HamerConfig()
+    sd = synth.hamer_state_dict(cfg, seed=0, bf16_representable=True)
+    mp = synth.mano_params(seed=0)
+    mean = 255.0 * np.array([0.485, 0.456, 0.406]); std = 255.0 * np.array([0.229, 0.224, 0.225])
+    batch = crop_ref.prepare_batch_bbox(frame, dets, mean, std)
+    with torch.no_grad():
+        o = R.hamer_forward(sd, mp, torch.from_numpy(batch["img"]), cfg)
+    # estimate_from_rgb, infer.py:381-476 (k_real branch)
+    do_flip = torch.from_numpy(batch["do_flip"])
+    cam = o["pred_cam"].clone()
+    cam[:, 1] *= 1.0 - 2.0 * do_flip
+    fx, fy, cx, cy = k_real[0, 0], k_real[1, 1], k_real[0, 2], k_real[1, 2]
+    bs = torch.from_numpy(batch["box_size"]) * cam[:, 0] + 1e-9
+    tz = 2 * fx / bs
+    tx = 2 * (torch.from_numpy(batch["box_center"])[:, 0] - cx) / bs + cam[:, 1]
+    ty = 2 * (torch.from_numpy(batch["box_center"])[:, 1] - cy) / bs + cam[:, 2]
+    if fx != fy:
+        ty = ty * (fx / fy)
+    cam_t_full = torch.stack([tx, ty, tz], -1)
+    kp3d = o["pred_keypoints_3d"].clone()
+    kp3d[:, :, 0] *= do_flip[:, None]
+    kc = kp3d + cam_t_full[:, None]
+    depth = kc[:, :, 2:3] + 1e-9
+    kp2d = torch.cat([kc[:, :, 0:1] / depth * fx + cx, kc[:, :, 1:2] / depth * fy + cy], -1)
+    return batch, o, cam_t_full, kp2d
+
+
+def test_estimate_from_rgb_matches_oracle_pipeline(hi):
+    frame = synth.frame_u8(720, 1280, seed=21).numpy()
+    dets = [["right", [300.0, 200.0, 460.0, 380.0]], ["left", [700.0, 300.0, 820.0, 470.0]], ["left", [1150.0, 600.0, 1300.0, 740.0]]]
+    k_real = np.array([[900.0, 0, 640.0], [0, 910.0, 360.0], [0, 0, 1]], dtype=np.float32)
+    out, params = hi.estimate_from_rgb(frame, dets, k_real)
+    batch, o, cam_t_full, kp2d = _oracle_pipeline(frame, dets, k_real)
+    assert np.array_equal(out["img"].cpu().numpy(), batch["img"])                      # crop: bit-exact
+    np.testing.assert_allclose(out["trans"].cpu().numpy(), batch["trans"], rtol=1e-6, atol=1e-5)
+    assert torch.equal(out["trans"], out["inv_trans"]) and out["do_flip"].tolist() == [0.0, 1.0, 1.0]
+    mp = out["pred_mano_params"]
+    assert mp["global_orient"].shape == (3, 1, 3, 3) and mp["hand_pose"].shape == (3, 15, 3, 3) and mp["betas"].shape == (3, 10)
+    np.testing.assert_allclose(mp["global_orient"].cpu().numpy(), o["global_orient"].numpy(), atol=1e-3)
+    np.testing.assert_allclose(mp["hand_pose"].cpu().numpy(), o["hand_pose"].numpy(), atol=1e-3)
+    np.testing.assert_allclose(mp["betas"].cpu().numpy(), o["betas"].numpy(), atol=1e-3)
+    np.testing.assert_allclose(out["pred_vertices"].cpu().numpy(), o["pred_vertices"].numpy(), atol=1e-3)
+    np.testing.assert_allclose(params["trans"].cpu().numpy(), o["pred_cam_t"].numpy(), rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(out["pred_cam_t_full"].cpu().numpy(), cam_t_full.numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out["pred_keypoints_2d_full"].cpu().numpy(), kp2d.numpy(), rtol=2e-3, atol=0.5)
+    assert (out["pred_keypoints_3d"][0, :, 0] == 0).all()                               # the reference's do_flip quirk
+
+
+def test_estimate_from_rgb_default_intrinsics_and_errors(hi):
+    frame = synth.frame_u8(480, 640, seed=3).numpy()
+    out, _ = hi.estimate_from_rgb(frame, [["right", [200.0, 100.0, 330.0, 260.0]]])
+    f = 5000.0 / 256.0 * 640.0
+    assert abs(float(out["focal_length"][0]) - f) < 1e-3 and out["pred_cam_t_full"].shape == (1, 3)
+    with pytest.raises(ValueError):
+        hi.estimate_from_rgb(frame, [])
+    with pytest.raises(ValueError):
+        hi.estimate_from_rgb(frame, [["right", [1.0, 2.0, 3.0]]])
+    out2, _ = hi.estimate_from_rgb(frame, [["right", [200.0, 100.0, 330.0, 260.0]]], depth_refine=0.6)
+    assert abs(float(out2["pred_cam_t_full"][0, 2]) - 0.6) < 1e-6
+
+
+def test_npy_record_and_obj_reconstruction(hi, tmp_path):
+    frame = synth.frame_u8(480, 640, seed=4).numpy()
+    dets = [["right", [100.0, 100.0, 230.0, 260.0]], ["left", [350.0, 200.0, 470.0, 330.0]]]
+    out, _ = hi.estimate_from_rgb(frame, dets, np.array([[600.0, 0, 320], [0, 600.0, 240], [0, 0, 1]], np.float32))
+    rec = {d[0]: hand_record(out, d[0] == "right", i) for i, d in enumerate(dets)}
+    for r in rec.values():
+        assert r["betas"].shape == (10,) and r["theta"].shape == (48,) and r["pose_hand"].shape == (45,) and r["cam_t"].shape == (3,)
+    # theta (axis-angle) -> rotation matrices reproduces the network's matrices (infer.py:65-83 round trip)
+    Rm = axis_angle_to_rotation_matrix_torch(torch.from_numpy(rec["right"]["theta"].reshape(16, 3)))
+    ref = torch.cat([out["pred_mano_params"]["global_orient"][0], out["pred_mano_params"]["hand_pose"][0]], 0).cpu()
+    np.testing.assert_allclose(Rm.numpy(), ref.numpy(), atol=2e-5)
+    np.save(tmp_path / "img0.npy", rec)
+    reconstruct_and_save_obj_with_wrapper(str(tmp_path), str(tmp_path / "obj"), hi)
+    lines = open(tmp_path / "obj" / "img0.obj").read().splitlines()
+    v = np.array([[float(t) for t in l.split()[1:]] for l in lines if l.startswith("v ")])
+    assert v.shape == (2 * 778, 3) and sum(l.startswith("f ") for l in lines) == 2 * 1538
+    np.testing.assert_allclose(v[:778], out["pred_vertices"][0].cpu().numpy() + rec["right"]["cam_t"], atol=2e-4)
+    left = out["pred_vertices"][1].cpu().numpy().copy(); left[:, 0] *= -1
+    np.testing.assert_allclose(v[778:], left + rec["left"]["cam_t"], atol=2e-4)
