@@ -1,13 +1,16 @@
 // Attention.forward core of the ViT backbone (vit.py:115-123): softmax(scale * q k^T) v for
-// 192 tokens, 16 heads of head_dim 80.  One workgroup (4 waves) per (crop, head); K and V^T
-// of the head are staged once in LDS (64 KB), each wave owns 48 queries (3 MFMA tiles).
+// 192 tokens, 16 heads of head_dim 80.  One workgroup (4 waves) per (crop, head); K and V of the
+// head are staged once in LDS (63 KB, plain 16-byte copies), each wave owns 48 queries (3 MFMA
+// tiles).  V is consumed TRANSPOSED (the A operand of O^T = V^T . P^T) straight from its row-major
+// image with ds_read_b64_tr_b16, the gfx950 transposing LDS read.
 //
 // Layout trick (no cross-lane traffic for P): scores are computed TRANSPOSED,
 // S^T = K . Q^T with mfma_16x16x32 (A = K rows, B = Q^T), so lane l holds, for query l&15,
 // keys 4*(l>>4)+r of every 16-key tile.  Two such tiles are exactly the 8 k-slots of lane l
 // for the next MFMA's B operand (P^T) if the 32 keys of a k-step are permuted as
 //   slot (g, j) -> key 4g + j (j < 4),  16 + 4g + (j - 4) (j >= 4),
-// and the A operand (V^T rows from LDS) is read with the same permutation (two 8-byte reads).
+// and the A operand (V^T) is read with the same permutation: two transposing 8-byte reads, each
+// returning 4 consecutive keys of one head-dim column.
 // O^T = V^T . P^T leaves 4 consecutive head-dim values of one query per lane, so the row sum
 // stays lane-local and the output goes out as 8-byte vectors.  Softmax statistics in fp32
 // (wavefront shuffles across the 4 lane groups), head_dim 80 is padded to 96 with zeros.
@@ -19,10 +22,18 @@ namespace {
 constexpr int T = 192;        // tokens (16 x 12 patches)
 constexpr int HD = 80;        // head dim
 constexpr int KSTR = 88;      // K row stride in LDS (elements): 176 B rows, conflict-free b128 reads
-constexpr int VSTR = 200;     // V^T row stride in LDS (elements): 400 B rows
+constexpr int VSTR = 80;      // V row stride in LDS (elements): 160 B = 40 dwords, 8 rows x 32 B tile the 64 banks
 constexpr int KS_BYTES = T * KSTR * 2;
-constexpr int VT_BYTES = HD * VSTR * 2;
-constexpr int ATT_LDS = KS_BYTES + VT_BYTES;   // 65,792 B -> 2 workgroups per CU
+constexpr int VT_BYTES = T * VSTR * 2;
+constexpr int ATT_LDS = KS_BYTES + VT_BYTES;   // 64,512 B -> 2 workgroups per CU
+
+// ds_read_b64_tr_b16: within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4 x 16 block; lane i receives column i of the 4 rows.  EXEC must be all ones.
+template <class V4> __device__ __forceinline__ V4 lds_read_tr4(const void* p) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(V4, v);
+}
 
 template <class TT>
 __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const typename TT::elem* __restrict__ qkv,
@@ -33,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const typename TT
   using vec8 = typename TT::vec8;
   using vec4 = typename TT::vec4;
   elem* Ks = (elem*)smem;
-  elem* Vt = (elem*)(smem + KS_BYTES);
+  elem* Vs = (elem*)(smem + KS_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
@@ -41,14 +52,11 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const typename TT
   const size_t ld = (size_t)3 * C;
   const elem* base = qkv + (size_t)b * T * ld + (size_t)h * HD;
 
-  // ---- stage K (row-major) and V (transposed) for this head
+  // ---- stage K and V (both row-major) for this head
   for (int c = tid; c < T * (HD / 8); c += 256) {
     const int t = c / (HD / 8), ch = c % (HD / 8);
-    const vec8 kv = *(const vec8*)(base + (size_t)t * ld + C + ch * 8);
-    *(vec8*)(Ks + t * KSTR + ch * 8) = kv;
-    const vec8 vv = *(const vec8*)(base + (size_t)t * ld + 2 * C + ch * 8);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * VSTR + t] = vv[i];
+    *(vec8*)(Ks + t * KSTR + ch * 8) = *(const vec8*)(base + (size_t)t * ld + C + ch * 8);
+    *(vec8*)(Vs + t * VSTR + ch * 8) = *(const vec8*)(base + (size_t)t * ld + 2 * C + ch * 8);
   }
   __syncthreads();
 
@@ -112,12 +120,13 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const typename TT
     elem* orow = out + ((size_t)b * T + q) * C + h * HD;
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) {
-      const elem* vrow = Vt + (dt * 16 + li) * VSTR + 4 * g;
+      // this lane's address inside the 4-key x 16-column block of its lane group: key 4g + (li>>2), column 4*(li&3)
+      const elem* vblk = Vs + (4 * g + (li >> 2)) * VSTR + dt * 16 + 4 * (li & 3);
       f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 6; ++kk) {
-        const vec4 lo = *(const vec4*)(vrow + 32 * kk);
-        const vec4 hi = *(const vec4*)(vrow + 32 * kk + 16);
+        const vec4 lo = lds_read_tr4<vec4>(vblk + (32 * kk) * VSTR);         // keys 32kk + 4g .. +3, column dt*16 + li
+        const vec4 hi = lds_read_tr4<vec4>(vblk + (32 * kk + 16) * VSTR);    // keys 32kk + 16 + 4g .. +3
         vec8 vf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { vf[i] = lo[i]; vf[4 + i] = hi[i]; }

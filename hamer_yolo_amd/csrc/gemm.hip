@@ -6,20 +6,22 @@
 //                       RepConv common.py:502-504, Detect yolo.py:151): X rows are output pixels, the K
 //                       axis walks (ky, kx, ci) of an NHWC tensor, out-of-image taps read a zero line.
 //
-// gfx950 design: 128 x (32*NI) x 64 block tile, 4 waves (2x2), each wave 64 x (16*NI) outputs as
-// NI x 4 MFMA 16x16x32 accumulators.  Both operands are K-contiguous and staged global->LDS with
-// 16-byte LDS-DMA (global_load_lds_dwordx4) into two buffers; the LDS image is lane-linear, so the
-// bank-conflict XOR swizzle (16-B chunk ^= row&7 inside each 128-B row) is applied to the per-lane
-// SOURCE address and again on the ds_read_b128 fragment reads.  The MFMA "A" operand is the W tile
-// and "B" the X tile, so a lane's 4 accumulator registers are 4 consecutive output columns of one
-// row: bias / residual / outputs move as 8- or 16-byte vectors.
+// gfx950 design.  Block tile (WM*MI*16) x (WN*NI*16) x 64 with WM x WN waves, each wave MI x NI MFMA
+// 16x16x32 accumulators.  Both operands are K-contiguous and staged global->LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4) into a ring of STAGES buffers; the ring is advanced with a COUNTED
+// s_waitcnt vmcnt(N) and a raw s_barrier, so STAGES-1 K-tiles of loads stay in flight across the
+// barrier (a __syncthreads would drain them).  The LDS image is lane-linear, so the bank-conflict XOR
+// swizzle (16-B chunk ^= row&7 inside each 128-B row) is applied to the per-lane SOURCE address and
+// again on the ds_read_b128 fragment reads.  The MFMA "A" operand is the W tile and "B" the X tile,
+// so a lane's 4 accumulator registers are 4 consecutive output columns of one row: bias / residual /
+// outputs move as 8- or 16-byte vectors.  Tiles are walked in an XCD-aware order.
+#include <stdlib.h>
 #include "common.h"
 #include "hamer_hip_internal.h"
 
 namespace {
 
-constexpr int BM = 128, BK = 64;
-constexpr int XTILE_BYTES = BM * BK * 2;          // 16 KB
+constexpr int BK_DEFAULT = 64;
 
 struct KArgs {                                    // kernel-side view of either entry point
   const void* X; const void* W; void* C; const float* bias; const float* resid;
@@ -29,12 +31,48 @@ struct KArgs {                                    // kernel-side view of either 
   int H, Wd, Hout, Wout, ksz, stride, pad, cin_log2, taps;
 };
 
-template <class T, int EPI, int NI, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const KArgs g) {
-  constexpr int BN = 32 * NI;
-  constexpr int WTILE_BYTES = BN * BK * 2;
+// GELU with the erf of Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below a 16-bit output ulp);
+// 1 + erf(-|z|) is formed without cancellation.  The fp32 decoder keeps the libm erff (common.h).
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float q = p * t * __expf(-z * z);             // 1 - erf(z)
+  return 0.5f * v * (v >= 0.f ? 2.0f - q : q);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N < 0, "add this vmcnt immediate");
+}
+
+template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+  constexpr int ROWB = BK * 2;                        // bytes per tile row in LDS (128 or 64)
+  constexpr int CH = BK / 8;                          // 16-byte chunks per row
+  constexpr int RPI = 1024 / ROWB;                    // rows covered by one 1-KiB LDS-DMA instruction
+  constexpr int XI = BM / NW / RPI, WI = BN / NW / RPI;   // staging instructions per wave and K-tile
+  static_assert(BK == 64 || BK == 32, "BK is 64 or 32");
+  static_assert(!CONV || BK == 64, "the implicit-GEMM loader is written for BK = 64");
+  static_assert(BM % (NW * RPI) == 0 && BN % (NW * RPI) == 0, "tile rows must split into whole DMA pieces per wave");
+  constexpr int XTILE_BYTES = BM * BK * 2, WTILE_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = XTILE_BYTES + WTILE_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  constexpr int LOADS = XI + WI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   using vec8 = typename T::vec8;
   using elem = typename T::elem;
 
@@ -43,20 +81,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const KArgs g) {
   const int tiles_n = (g.N + BN - 1) / BN;
   const int wgid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (wgid / tiles_n) * BM, n0 = (wgid % tiles_n) * BN;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
   const elem* __restrict__ X = (const elem*)g.X;
   const elem* __restrict__ W = (const elem*)g.W;
 
-  // staging geometry: wave w loads X rows [32w, 32w+32) and W rows [8*NI*w, 8*NI*(w+1)); one
-  // instruction = 8 rows x 128 B; lane -> (row = lane>>3, physical 16-B chunk = lane&7)
-  const int chunk = (lane & 7) ^ ((lane >> 3) & 7);       // logical chunk of this lane (same for all its rows)
-  const elem* xsrc[4];
-  int pix_y[4], pix_x[4];
-  const elem* wsrc[NI];
+  // staging geometry: wave w loads X rows [XI*RPI*w, +XI*RPI) and W rows [WI*RPI*w, +WI*RPI); lane -> (row =
+  // lane / CH, physical 16-B chunk = lane % CH); logical chunk = physical ^ key(row) with key = row & 7 for
+  // 128-B rows and (row >> 2) & 3 for 64-B rows (4 rows share a 256-B bank row)
+  const int srow = lane / CH;
+  const int chunk = (lane % CH) ^ (BK == 64 ? (srow & 7) : ((srow >> 2) & 3));
+  const elem* xsrc[XI];
+  int pix_y[XI], pix_x[XI];
+  const elem* wsrc[WI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int gm = m0 + wave * 32 + i * 8 + (lane >> 3);
+  for (int i = 0; i < XI; ++i) {
+    int gm = m0 + wave * XI * RPI + i * RPI + srow;
     gm = gm < g.M ? gm : g.M - 1;                          // edge rows: valid memory, never stored
     if (CONV) {
       const int hw = g.Hout * g.Wout;
@@ -71,71 +111,84 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const KArgs g) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    int gn = n0 + wave * 8 * NI + i * 8 + (lane >> 3);
+  for (int i = 0; i < WI; ++i) {
+    int gn = n0 + wave * WI * RPI + i * RPI + srow;
     gn = gn < g.N ? gn : g.N - 1;
     wsrc[i] = W + (size_t)gn * g.ldw + chunk * 8;
   }
 
   auto stage = [&](int buf, int kt) {
-    char* lx = smem + buf * STAGE_BYTES + wave * 32 * 128;
-    char* lw = smem + buf * STAGE_BYTES + XTILE_BYTES + wave * 8 * NI * 128;
+    char* lx = smem + buf * STAGE_BYTES + wave * XI * 1024;
+    char* lw = smem + buf * STAGE_BYTES + XTILE_BYTES + wave * WI * 1024;
     if (CONV) {
       const int k = kt * BK + chunk * 8;
       const int tap = k >> g.cin_log2, ci = k & ((1 << g.cin_log2) - 1);
       const int ky = tap / g.ksz, kx = tap - ky * g.ksz;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < XI; ++i) {
         const int iy = pix_y[i] + ky, ix = pix_x[i] + kx;
         const bool ok = tap < g.taps && iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
         const elem* src = ok ? xsrc[i] + ((size_t)iy * g.Wd + ix) * g.ldx + ci : (const elem*)g.zeros;
-        glds16(src, lx + i * 8 * 128);
+        glds16(src, lx + i * 1024);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(xsrc[i] + kt * BK, lx + i * 8 * 128);
+      for (int i = 0; i < XI; ++i) glds16(xsrc[i] + kt * BK, lx + i * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < NI; ++i) glds16(wsrc[i] + kt * BK, lw + i * 8 * 128);
+    for (int i = 0; i < WI; ++i) glds16(wsrc[i] + kt * BK, lw + i * 1024);
   };
 
-  f32x4_t acc[NI][4];
+  f32x4_t acc[NI][MI];
 #pragma unroll
   for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // fragment reads: row = tile_row + (lane&15); 16-B chunk = ks*4 + (lane>>4), swizzled by row&7
-  const int frow = lane & 15, fsw = lane & 7, fch = lane >> 4;
-  auto compute = [&](int buf) {
+  // fragment reads: row = tile_row + (lane&15); 16-B chunk = ks*4 + (lane>>4), swizzled with the staging key
+  const int frow = lane & 15, fsw = BK == 64 ? (lane & 7) : ((lane >> 2) & 3), fch = lane >> 4;
+  // one K sub-step (32 deep): fragment reads + NI x MI MFMAs
+  auto substep = [&](int buf, int ks) {
     const char* lx = smem + buf * STAGE_BYTES;
     const char* lw = lx + XTILE_BYTES;
+    const int coff = ((ks * 4 + fch) ^ fsw) * 16;
+    vec8 wf[NI], xf[MI];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((ks * 4 + fch) ^ fsw) * 16;
-      vec8 wf[NI], xf[4];
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
 #pragma unroll
-      for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * 128 + coff);
+    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    if (SCHED >= 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *(const vec8*)(lx + (wr * 64 + i * 16 + frow) * 128 + coff);
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
-    }
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
+    if (SCHED >= 1) __builtin_amdgcn_s_setprio(0);
   };
 
+  // ---- K loop: ring of STAGES buffers, STAGES-1 tiles of LDS-DMA in flight across the barrier
   const int nk = g.K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) stage(s, s);
+  int rd = 0, wrb = STAGES - 1;                        // ring slots: read tile kt, write tile kt+STAGES-1
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
+    // tile kt must have landed: in steady state the STAGES-2 newer tiles may still be in flight
+    if (kt + STAGES - 2 < nk) wait_vmcnt<LOADS * (STAGES - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                      // everyone's tile kt landed; everyone is done reading slot wrb
+    const bool more = kt + STAGES - 1 < nk;
+    if (SCHED <= 1) {                                  // loads first, then the whole tile
+      if (more) stage(wrb, kt + STAGES - 1);
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) substep(rd, ks);
+    } else {                                           // first sub-step, then the loads, then the rest
+      substep(rd, 0);
+      if (more) stage(wrb, kt + STAGES - 1);
+#pragma unroll
+      for (int ks = 1; ks < BK / 32; ++ks) substep(rd, ks);
+    }
+    rd = rd + 1 == STAGES ? 0 : rd + 1;
+    wrb = wrb + 1 == STAGES ? 0 : wrb + 1;
   }
 
   // ---- epilogue: lane holds C[m][n..n+3], m = ..+(lane&15), n = ..+4*(lane>>4)
@@ -147,13 +200,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const KArgs g) {
     f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *(const f32x4_t*)(bias + n);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = m0 + wr * 64 + mi * 16 + (lane & 15);
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wr * 16 * MI + mi * 16 + (lane & 15);
       if (m >= g.M) continue;
       f32x4_t v = acc[ni][mi] + bv;
       if (EPI == HM_EPI_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
       } else if (EPI == HM_EPI_SILU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
@@ -174,45 +227,103 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const KArgs g) {
   }
 }
 
-template <class T, int NI, bool CONV>
-int launch_epi(const KArgs& g, int epilogue, hipStream_t s, const char* what) {
-  constexpr int BN = 32 * NI;
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  dim3 grid(tiles), block(256);
-  switch (epilogue) {
-    case HM_EPI_STORE: hipLaunchKernelGGL((gemm_tn_kernel<T, HM_EPI_STORE, NI, CONV>), grid, block, 0, s, g); break;
-    case HM_EPI_SILU: hipLaunchKernelGGL((gemm_tn_kernel<T, HM_EPI_SILU, NI, CONV>), grid, block, 0, s, g); break;
-    case HM_EPI_F32: hipLaunchKernelGGL((gemm_tn_kernel<T, HM_EPI_F32, NI, CONV>), grid, block, 0, s, g); break;
-    case HM_EPI_GELU:
-      if (CONV) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unsupported epilogue");
-      hipLaunchKernelGGL((gemm_tn_kernel<T, HM_EPI_GELU, NI, false>), grid, block, 0, s, g); break;
-    case HM_EPI_RESID_F32:
-      if (CONV) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unsupported epilogue");
-      hipLaunchKernelGGL((gemm_tn_kernel<T, HM_EPI_RESID_F32, NI, false>), grid, block, 0, s, g); break;
-    default: return hm_set_error(HM_ERR_ARG, "unknown epilogue");
+template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
+int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
+  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+  constexpr int LDS = STAGES * (BM + BN) * BK * 2;
+  auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return hm_set_error(HM_ERR_HIP, "gemm: cannot raise the dynamic LDS limit");
+    attr_set = true;
   }
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, s, g);
   return hm_check_launch(what);
 }
 
-template <class T, bool CONV>
-int launch_ni(const KArgs& g, int epilogue, hipStream_t s, const char* what) {
-  if constexpr (!CONV) {
-    return launch_epi<T, 4, false>(g, epilogue, s, what);
-  } else {
-    if (g.N > 64) return launch_epi<T, 4, true>(g, epilogue, s, what);
-    if (g.N > 32) return launch_epi<T, 2, true>(g, epilogue, s, what);
-    return launch_epi<T, 1, true>(g, epilogue, s, what);
+// Tile configurations of the plain GEMM (hm_gemm).  HM_GEMM_VARIANT / hm_gemm_set_variant select one
+// for tuning runs; the default is chosen per shape in pick_variant().
+int g_variant = -2;    // -2: read HM_GEMM_VARIANT on first use; -1: per-shape default
+
+template <class T, int EPI>
+int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
+  switch (variant) {
+    case 0: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false>(g, s, "hm_gemm");   // 128x128, 4 waves, 2 stages (64 KB, 2 blocks/CU)
+    case 1: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false>(g, s, "hm_gemm");   // 256x128, 8 waves, 3 stages (144 KB)
+    case 2: return launch_cfg<T, EPI, 2, 4, 8, 4, 2, false>(g, s, "hm_gemm");   // 256x256, 8 waves, 2 stages (128 KB)
+    case 3: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false>(g, s, "hm_gemm");   // 256x128, 8 waves, 2 stages (96 KB)
+    case 4: return launch_cfg<T, EPI, 2, 2, 4, 4, 3, false>(g, s, "hm_gemm");   // 128x128, 4 waves, 3 stages (96 KB, 1 block/CU)
+    case 5: return launch_cfg<T, EPI, 2, 2, 8, 4, 3, false>(g, s, "hm_gemm");   // 256x128, 4 waves (128x64 each), 3 stages (144 KB)
+    case 6: return launch_cfg<T, EPI, 2, 4, 8, 4, 4, false, 32>(g, s, "hm_gemm");   // 256x256x32, 8 waves, 4 stages (128 KB)
+    case 7: return launch_cfg<T, EPI, 2, 4, 8, 4, 3, false, 32>(g, s, "hm_gemm");   // 256x256x32, 8 waves, 3 stages (96 KB)
+    case 8: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false>(g, s, "hm_gemm");       // 256x256, waves 4x2 (64x128 each), 2 stages
+    case 9: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 1>(g, s, "hm_gemm");   // + s_setprio around the MFMA cluster
+    case 10: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");  // + loads issued between the two sub-steps
+    case 11: return launch_cfg<T, EPI, 4, 2, 4, 8, 4, false, 32, 1>(g, s, "hm_gemm");  // 256x256x32, 4 stages, setprio
+    default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
+  }
+}
+
+// Default tile choice (measured on MI355X, interleaved A/B on the ViT-H shapes at M = 12288, random data):
+// the 256x256 tile halves the LDS-DMA bytes per flop of the 128x128 one (the kernel is bound by the per-CU
+// global->LDS fill rate, not by the MFMA pipe); loads issued between the two 32-deep sub-steps win for short
+// K, loads-first wins for K >= 2560.  Small problems keep the 128x128 tile (less padding waste, 2 blocks/CU).
+int pick_variant(const KArgs& g) {
+  if (g_variant == -2) {
+    const char* e = getenv("HM_GEMM_VARIANT");
+    g_variant = e ? atoi(e) : -1;
+  }
+  if (g_variant >= 0) return g_variant;
+  if (g.M < 1024 || g.N < 512) return 0;
+  return g.K >= 2560 ? 9 : 10;
+}
+
+template <class T>
+int launch_gemm_epi(const KArgs& g, int epilogue, hipStream_t s) {
+  const int v = pick_variant(g);
+  switch (epilogue) {
+    case HM_EPI_STORE: return launch_gemm<T, HM_EPI_STORE>(g, v, s);
+    case HM_EPI_GELU: return launch_gemm<T, HM_EPI_GELU>(g, v, s);
+    case HM_EPI_RESID_F32: return launch_gemm<T, HM_EPI_RESID_F32>(g, v, s);
+    case HM_EPI_F32: return launch_gemm<T, HM_EPI_F32>(g, v, s);
+    case HM_EPI_SILU: return launch_gemm<T, HM_EPI_SILU>(g, v, s);
+    default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown epilogue");
+  }
+}
+
+template <class T, int EPI>
+int launch_conv_ni(const KArgs& g, hipStream_t s) {
+  if (g.N > 64) return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true>(g, s, "hm_conv2d_nhwc");
+  if (g.N > 32) return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true>(g, s, "hm_conv2d_nhwc");
+  return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true>(g, s, "hm_conv2d_nhwc");
+}
+
+template <class T>
+int launch_conv(const KArgs& g, int epilogue, hipStream_t s) {
+  switch (epilogue) {
+    case HM_EPI_STORE: return launch_conv_ni<T, HM_EPI_STORE>(g, s);
+    case HM_EPI_SILU: return launch_conv_ni<T, HM_EPI_SILU>(g, s);
+    case HM_EPI_F32: return launch_conv_ni<T, HM_EPI_F32>(g, s);
+    default: return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unsupported epilogue");
   }
 }
 
 }  // namespace
+
+extern "C" int hm_gemm_set_variant(int v) {
+  if (v < -1 || v > 11) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) .. 11");
+  g_variant = v;
+  return HM_OK;
+}
 
 extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a) return hm_set_error(HM_ERR_ARG, "hm_gemm: null args");
   const hm_gemm_args& g = *a;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hm_set_error(HM_ERR_ARG, "hm_gemm: empty problem");
-  if (g.K % BK != 0) return hm_set_error(HM_ERR_ARG, "hm_gemm: K must be a multiple of 64");
+  if (g.K % BK_DEFAULT != 0) return hm_set_error(HM_ERR_ARG, "hm_gemm: K must be a multiple of 64");
   if (g.N % 4 != 0 || g.ldc % 4 != 0) return hm_set_error(HM_ERR_ARG, "hm_gemm: N and ldc must be multiples of 4");
   if (g.ldx % 8 != 0 || g.ldw % 8 != 0) return hm_set_error(HM_ERR_ARG, "hm_gemm: ldx/ldw must be multiples of 8 elements");
   if (g.ldx < g.K || g.ldw < g.K || g.ldc < g.N) return hm_set_error(HM_ERR_ARG, "hm_gemm: leading dimension too small");
@@ -225,8 +336,8 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
   k.X = g.X; k.W = g.W; k.C = g.C; k.bias = g.bias; k.resid = g.resid;
   k.M = g.M; k.N = g.N; k.K = g.K; k.ldx = g.ldx; k.ldw = g.ldw; k.ldc = g.ldc; k.ldr = g.ldr; k.resid_mod = g.resid_mod;
   HmProfScope prof(HM_K_GEMM, g.epilogue, g.M, g.N, g.K, stream);
-  if (g.dtype == HM_DTYPE_BF16) return launch_ni<TBf16, false>(k, g.epilogue, stream, "hm_gemm");
-  if (g.dtype == HM_DTYPE_F16) return launch_ni<TF16, false>(k, g.epilogue, stream, "hm_gemm");
+  if (g.dtype == HM_DTYPE_BF16) return launch_gemm_epi<TBf16>(k, g.epilogue, stream);
+  if (g.dtype == HM_DTYPE_F16) return launch_gemm_epi<TF16>(k, g.epilogue, stream);
   return hm_set_error(HM_ERR_ARG, "hm_gemm: dtype must be HM_DTYPE_BF16 or HM_DTYPE_F16");
 }
 
@@ -242,7 +353,7 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   while ((1 << lg) < c.Cin) ++lg;
   if ((1 << lg) != c.Cin || c.Cin < 8) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: Cin must be a power of two >= 8");
   const int taps = c.ksize * c.ksize, ktrue = taps * c.Cin;
-  if (c.Kpad % BK != 0 || c.Kpad < ktrue) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: Kpad must be a multiple of 64 covering k*k*Cin");
+  if (c.Kpad % BK_DEFAULT != 0 || c.Kpad < ktrue) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: Kpad must be a multiple of 64 covering k*k*Cin");
   if (c.Cout % 4 != 0 || c.ldy % 4 != 0 || c.ldy < c.Cout || c.ldx % 8 != 0 || c.ldx < c.Cin)
     return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: Cout % 4, ldy % 4, ldx % 8 must be 0 and cover the channels");
   if ((((uintptr_t)c.X | (uintptr_t)c.W | (uintptr_t)c.zeros | (uintptr_t)c.bias) & 15) || ((uintptr_t)c.Y & 7))
@@ -257,7 +368,7 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   if (c.out_f32 && c.act) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: f32 output has no activation");
   const int epi = c.out_f32 ? HM_EPI_F32 : (c.act ? HM_EPI_SILU : HM_EPI_STORE);
   HmProfScope prof(HM_K_CONV, c.ksize * 10 + c.stride, k.M, k.N, ktrue, stream);
-  if (c.dtype == HM_DTYPE_BF16) return launch_ni<TBf16, true>(k, epi, stream, "hm_conv2d_nhwc");
-  if (c.dtype == HM_DTYPE_F16) return launch_ni<TF16, true>(k, epi, stream, "hm_conv2d_nhwc");
+  if (c.dtype == HM_DTYPE_BF16) return launch_conv<TBf16>(k, epi, stream);
+  if (c.dtype == HM_DTYPE_F16) return launch_conv<TF16>(k, epi, stream);
   return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: bad dtype");
 }

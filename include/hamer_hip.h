@@ -54,6 +54,10 @@ typedef struct hm_gemm_args {
  * Attention.qkv/.proj (vit.py:114,:124), Mlp.fc1/.fc2 (vit.py:83,:85), PatchEmbed.proj
  * (vit.py:172, after hm_patch_im2col) and CrossAttention.to_kv (pose_transformer.py:114). */
 int hm_gemm(const hm_gemm_args* args, void* stream);
+/* Tuning hook: pin the GEMM tile configuration (0..5, see gemm.hip); -1 restores the default
+ * (also settable through the HM_GEMM_VARIANT environment variable).  Results do not depend on it
+ * beyond fp32 summation order. */
+int hm_gemm_set_variant(int variant);
 
 /* nn.LayerNorm over the last dim (vit.py:136,:144,:252 eps 1e-6; t_cond_mlp.py:51-52 eps 1e-5).
  * x [M][D] f32 -> out [M][D]; out_dtype: HM_DTYPE_BF16 / HM_DTYPE_F16 / HM_OUT_F32. */

@@ -43,6 +43,24 @@ def test_gemm_exact_integers_asymmetric():
         assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize("variant", list(range(12)))
+def test_gemm_tile_variants_exact(variant):
+    """Every tile / pipeline configuration of gemm.hip on exact-integer data (bit-exact whatever the
+    summation order), ragged M and N, several K-tile counts (ring prologue / steady state / tail)."""
+    lib = L.load()
+    try:
+        L.check(lib.hm_gemm_set_variant(variant))
+        for (M, N, K) in ((300, 260, 64), (513, 388, 128), (1000, 1284, 448)):
+            x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+            w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+            bias = (torch.arange(N) % 9 - 4).float()
+            ref = x @ w.t() + bias
+            out = ops.gemm(x.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16), bias.to(DEV), L.HM_EPI_F32)
+            assert torch.equal(out.cpu(), ref), (variant, M, N, K)
+    finally:
+        lib.hm_gemm_set_variant(-1)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(384, 1280, 768), (192, 3840, 1280), (200, 132, 64), (64, 6144, 1280), (1, 4, 64)])
 def test_gemm_epilogues(M, N, K, dt):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of GEMM tile variants on the ViT-H shapes (random data): ROUNDS rounds, every round runs
+every variant REPS times per shape; reports the median over all launches of a variant.  One process, one
+device, variants interleaved so clock drift hits them equally.  Env: VARIANTS=8,9,10 ROUNDS=6 REPS=5"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hamer_yolo_amd import lib as L
+from hamer_yolo_amd import ops
+
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,8").split(",")]
+rounds, reps = int(os.environ.get("ROUNDS", 6)), int(os.environ.get("REPS", 5))
+M = int(os.environ.get("BATCH", 64)) * 192
+dev = "cuda"
+torch.manual_seed(0)
+shapes = [("qkv", 1280, 3840, L.HM_EPI_STORE), ("proj", 1280, 1280, L.HM_EPI_RESID_F32), ("fc1", 1280, 5120, L.HM_EPI_GELU),
+          ("fc2", 5120, 1280, L.HM_EPI_RESID_F32)]
+lib = L.load()
+res = {}
+for (name, K, N, epi) in shapes:
+    x = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    b = torch.randn(N, device=dev)
+    f32 = epi == L.HM_EPI_RESID_F32
+    out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    r = torch.randn(M, N, device=dev) if f32 else None
+    times = {v: [] for v in variants}
+    for v in variants:                        # warm
+        L.check(lib.hm_gemm_set_variant(v)); ops.gemm(x, w, b, epi, resid=r, out=out)
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for v in variants:
+            L.check(lib.hm_gemm_set_variant(v))
+            with L.profile(capacity=reps + 2) as prof:
+                for _ in range(reps):
+                    ops.gemm(x, w, b, epi, resid=r, out=out)
+                torch.cuda.synchronize()
+            times[v] += [rec[5] for rec in prof.records]
+    for v in variants:
+        t = sorted(times[v]); med = t[len(t) // 2]
+        res[(name, v)] = med
+        print(f"{name:5s} v{v:<3d} median {med*1e3:7.1f} us  min {t[0]*1e3:7.1f}  {2.0*M*N*K/med/1e9:7.1f} TF", flush=True)
+print("per-layer sum (us):", {v: round(sum(res[(n, v)] for n, *_ in shapes) * 1e3, 1) for v in variants})
