@@ -26,6 +26,7 @@ constexpr int BK_DEFAULT = 64;
 struct KArgs {                                    // kernel-side view of either entry point
   const void* X; const void* W; void* C; const float* bias; const float* resid;
   int M, N, K, ldx, ldw, ldc, ldr, resid_mod;
+  int group_m;                                    // tile order: runs of group_m M-tiles per N-tile (L2 reuse of both panels)
   // convolution geometry (CONV only)
   const void* zeros;
   int H, Wd, Hout, Wout, ksz, stride, pad, cin_log2, taps;
@@ -44,6 +45,19 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return 0.5f * v * (v >= 0.f ? 2.0f - q : q);
 }
 
+// Tile walk.  Blocks b, b+8, .. share an XCD (and its 4 MB L2); xcd_remap gives every XCD a contiguous run of
+// tile ids, and inside that run tiles are ordered in super-rows of `group_m` M-tiles, M fastest, so the ~32
+// tiles an XCD works on at once form a group_m x (32 / group_m) rectangle: group_m A panels and 32/group_m W
+// panels stream through its L2 once per round instead of 2 + tiles_n (PMC: FETCH_SIZE of the N = 3840..6144
+// GEMMs was 9-13x their algorithmic bytes with the plain row-major walk).
+__device__ __forceinline__ void tile_coords(int wgid, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+  const int per_super = group_m * tiles_n;
+  const int super = wgid / per_super, r = wgid - super * per_super;
+  const int rows = min(group_m, tiles_m - super * group_m);     // the last super-row may be short
+  tn = r / rows;
+  tm = super * group_m + (r - tn * rows);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -56,6 +70,89 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else static_assert(N < 0, "add this vmcnt immediate");
+}
+
+constexpr int epi_cgn(int MI, int NI) { return NI < 16 / MI ? NI : 16 / MI; }
+constexpr int epi_stage_bytes(int MI, int NI) { return MI * 16 * epi_cgn(MI, NI) * 64; }
+
+// Epilogue of one wave through LDS.  acc[ni][mi] holds C[mb + mi*16 + (lane&15)][nb + ni*16 + 4*(lane>>4) .. +3]
+// (the MFMA accumulator layout: 16 rows x 16-byte pieces per store).  Written straight from that layout every
+// store instruction touches 16 rows with 32-64 B each (PMC: WRITE_SIZE 1.4-1.7x the output bytes) and the
+// residual loads form 32 dependent load->add->store chains per wave; measured, that epilogue was 30-40 % of the
+// GEMM time.  Instead each wave transposes its tile through a private 16 KB LDS region (the K-loop ring is free
+// by then), in column groups of 64: accumulator pieces are written with a 16-byte-chunk XOR swizzle
+// (chunk ^= row & 15: conflict-free for the 16 rows of a piece), read back row-major, and every global
+// instruction then covers 4 full 256-byte row segments (128 B for 16-bit outputs).  Residual rows are fetched
+// row-major too, all issued before the LDS round trip so their latency overlaps it.
+template <class T, int EPI, int MI, int NI>
+__device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI], int mb, int nb, int lane, char* wlds) {
+  using elem = typename T::elem;
+  // n-subtiles per column group: <= 16 KB of LDS per wave; the residual epilogue splits that between the
+  // transposed accumulators and the residual rows, which arrive by LDS-DMA (no registers, all in flight at once)
+  constexpr int CGN0 = epi_cgn(MI, NI);
+  constexpr bool RES = EPI == HM_EPI_RESID_F32;
+  constexpr int CGN = (RES && CGN0 > 1) ? CGN0 / 2 : CGN0;
+  constexpr int NCH = CGN * 4;                     // 16-byte chunks per staged row (4, 8 or 16)
+  constexpr int RS = NCH * 16;                     // staged row stride in bytes
+  constexpr int RPI = 64 / NCH;                    // rows per row-major instruction (1 KiB)
+  constexpr int ITS = MI * 16 / RPI;               // row-major instructions per column group
+  const int arow = lane & 15, apiece = lane >> 4;  // accumulator layout
+  const int rrow = lane / NCH, rslot = lane % NCH; // row-major layout
+  const float* __restrict__ bias = g.bias;
+  char* rlds = wlds + MI * 16 * RS;                // residual rows (RES only)
+#pragma unroll
+  for (int cg = 0; cg < NI / CGN; ++cg) {
+    const int ncol0 = nb + cg * CGN * 16;
+    if (RES) {                                     // residual rows -> LDS, row-major, same (row, slot) image as the reads below
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int row = it * RPI + rrow;
+        int m = mb + row, n = ncol0 + ((rslot ^ (row & (NCH - 1))) << 2);
+        m = m < g.M ? m : g.M - 1;                 // out-of-range lanes fetch a valid address; their result is never stored
+        n = n < g.N ? n : 0;
+        const int rm = g.resid_mod > 0 ? m % g.resid_mod : m;
+        glds16(g.resid + (size_t)rm * g.ldr + n, rlds + it * 1024);
+      }
+    }
+    // accumulator layout -> LDS (16-byte chunk XOR swizzle)
+#pragma unroll
+    for (int nl = 0; nl < CGN; ++nl)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = mi * 16 + arow;
+        const int slot = (nl * 4 + apiece) ^ (row & (NCH - 1));
+        *(f32x4_t*)(wlds + row * RS + slot * 16) = acc[cg * CGN + nl][mi];
+      }
+    if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // LDS -> row-major, bias / activation / residual, coalesced stores
+#pragma unroll 2
+    for (int it = 0; it < ITS; ++it) {
+      const int row = it * RPI + rrow, m = mb + row;
+      const int n = ncol0 + ((rslot ^ (row & (NCH - 1))) << 2);
+      f32x4_t v = *(const f32x4_t*)(wlds + row * RS + rslot * 16);
+      f32x4_t r = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (RES) r = *(const f32x4_t*)(rlds + row * RS + rslot * 16);
+      if (m >= g.M || n >= g.N) continue;
+      if (bias) v += *(const f32x4_t*)(bias + n);
+      if (EPI == HM_EPI_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
+      } else if (EPI == HM_EPI_SILU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+      }
+      if (RES) {
+        *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v + r;
+      } else if (EPI == HM_EPI_F32) {
+        *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v;
+      } else {
+        typename T::vec4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (elem)v[q];
+        *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n) = o;
+      }
+    }
+  }
 }
 
 template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
@@ -78,9 +175,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int wgid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (wgid / tiles_n) * BM, n0 = (wgid % tiles_n) * BN;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
   const int wr = wave / WN, wc = wave % WN;
 
   const elem* __restrict__ X = (const elem*)g.X;
@@ -206,46 +304,152 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     wrb = wrb + 1 == STAGES ? 0 : wrb + 1;
   }
 
-  // ---- epilogue: lane holds C[m][n..n+3], m = ..+(lane&15), n = ..+4*(lane>>4)
-  const float* __restrict__ bias = g.bias;
+  __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring: reuse it for the epilogue
+  if (SCHED == 96) {                                    // ablation: no epilogue (keep the accumulators alive)
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wc * 16 * NI + ni * 16 + (lane >> 4) * 4;
-    if (n >= g.N) continue;
-    f32x4_t bv = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *(const f32x4_t*)(bias + n);
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wr * 16 * MI + mi * 16 + (lane & 15);
-      if (m >= g.M) continue;
-      f32x4_t v = acc[ni][mi] + bv;
-      if (EPI == HM_EPI_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      } else if (EPI == HM_EPI_SILU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-      }
-      if (EPI == HM_EPI_RESID_F32) {
-        const int rm = g.resid_mod > 0 ? m % g.resid_mod : m;
-        v += *(const f32x4_t*)(g.resid + (size_t)rm * g.ldr + n);
-        *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v;
-      } else if (EPI == HM_EPI_F32) {
-        *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v;
-      } else {
-        typename T::vec4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (elem)v[r];
-        *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n) = o;
-      }
-    }
+      for (int b = 0; b < MI; ++b) asm volatile("" :: "v"(acc[a][b]));
+    return;
   }
+  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI));
+}
+
+// Software-pipelined variant for the big plain GEMMs: 256x256 tile, K slabs of 32 in a 4-deep LDS ring
+// (3 slabs of LDS-DMA in flight), and the MFMA fragments DOUBLE-BUFFERED in registers: while the MFMAs of
+// slab t run, the ds_reads of slab t+1 and the LDS-DMA of slab t+3 are already issued, so after the one
+// barrier per slab every wave has matrix work ready (the plain kernel above reads its fragments right after
+// the barrier, when both waves of a SIMD stall on LDS together).
+template <class T, int EPI, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_pipe_kernel(const KArgs g) {
+  constexpr int BK = 32, STAGES = 4;
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+  constexpr int ROWB = 64, CH = 4, RPI = 16;
+  constexpr int XI = BM / NW / RPI, WI = BN / NW / RPI;
+  static_assert(BM % (NW * RPI) == 0 && BN % (NW * RPI) == 0, "tile rows must split into whole DMA pieces per wave");
+  constexpr int XTILE_BYTES = BM * BK * 2, WTILE_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = XTILE_BYTES + WTILE_BYTES;
+  constexpr int LOADS = XI + WI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using vec8 = typename T::vec8;
+  using elem = typename T::elem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wr = wave / WN, wc = wave % WN;
+  const elem* __restrict__ X = (const elem*)g.X;
+  const elem* __restrict__ W = (const elem*)g.W;
+
+  const int srow = lane / CH;
+  const int chunk = (lane % CH) ^ ((srow >> 2) & 3);
+  const elem* xsrc[XI];
+  const elem* wsrc[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    int gm = m0 + wave * XI * RPI + i * RPI + srow;
+    gm = gm < g.M ? gm : g.M - 1;
+    xsrc[i] = X + (size_t)gm * g.ldx + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int gn = n0 + wave * WI * RPI + i * RPI + srow;
+    gn = gn < g.N ? gn : g.N - 1;
+    wsrc[i] = W + (size_t)gn * g.ldw + chunk * 8;
+  }
+  auto stage = [&](int t) {
+    char* lx = smem + (t & (STAGES - 1)) * STAGE_BYTES + wave * XI * 1024;
+    char* lw = smem + (t & (STAGES - 1)) * STAGE_BYTES + XTILE_BYTES + wave * WI * 1024;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) glds16(xsrc[i] + (size_t)t * BK, lx + i * 1024);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) glds16(wsrc[i] + (size_t)t * BK, lw + i * 1024);
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  const int coff = (fch ^ ((lane >> 2) & 3)) * 16;
+  const int woff = (wc * 16 * NI + frow) * ROWB + coff, xoff = (wr * 16 * MI + frow) * ROWB + coff;
+  auto read_frags = [&](int t, vec8 (&wf)[NI], vec8 (&xf)[MI]) {
+    const char* lx = smem + (t & (STAGES - 1)) * STAGE_BYTES;
+    const char* lw = lx + XTILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + woff + i * 16 * ROWB);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + xoff + i * 16 * ROWB);
+  };
+  auto mfmas = [&](vec8 (&wf)[NI], vec8 (&xf)[MI]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // one slab: make slab t+1 visible, prefetch its fragments and the LDS-DMA of slab t+3, run the MFMAs of slab t
+  auto step = [&](int t, int nk, vec8 (&wc_)[NI], vec8 (&xc_)[MI], vec8 (&wn_)[NI], vec8 (&xn_)[MI]) {
+    if (t + 1 < nk) {
+      if (t + 2 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();      // slab t+1 landed (slab t+2 may be in flight)
+      __builtin_amdgcn_s_barrier();
+      read_frags(t + 1, wn_, xn_);
+      if (t + 3 < nk) stage(t + 3);                                    // overwrites slab t-1: consumed before this barrier
+    }
+    mfmas(wc_, xc_);
+    // the fragment reads issued above had the whole MFMA phase to land: retire them here (free), with the
+    // compiler-visible builtin, so that across the loop back-edge hipcc does not put an lgkmcnt(0) between
+    // the next slab's ds_reads and its MFMAs (0xC07F = lgkmcnt(0) only)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  };
+
+  const int nk = g.K / BK;                                             // host guarantees nk >= 4
+  stage(0); stage(1); stage(2);
+  wait_vmcnt<2 * LOADS>();
+  __builtin_amdgcn_s_barrier();
+  vec8 wa[NI], xa[MI], wb[NI], xb[MI];
+  read_frags(0, wa, xa);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                                 // nothing pending on any edge into the loop
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    step(t, nk, wa, xa, wb, xb);
+    step(t + 1, nk, wb, xb, wa, xa);
+  }
+  if (t < nk) step(t, nk, wa, xa, wb, xb);
+  __builtin_amdgcn_s_barrier();
+  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI));
+}
+
+template <class T, int EPI, int WM, int WN, int MI, int NI>
+int launch_pipe(const KArgs& g, hipStream_t s) {
+  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+  constexpr int RING = 4 * (BM + BN) * 32 * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI);
+  constexpr int LDS = RING > EPIB ? RING : EPIB;
+  auto kern = gemm_pipe_kernel<T, EPI, WM, WN, MI, NI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return hm_set_error(HM_ERR_HIP, "gemm: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  if (g.K < 128) return hm_set_error(HM_ERR_ARG, "hm_gemm: the pipelined tile needs K >= 128");
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, s, g);
+  return hm_check_launch("hm_gemm");
 }
 
 template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
 int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
-  constexpr int LDS = STAGES * (BM + BN) * BK * 2;
+  constexpr int RING = STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI);
+  constexpr int LDS = RING > EPIB ? RING : EPIB;
   auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -260,6 +464,7 @@ int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
 
 // Tile configurations of the plain GEMM (hm_gemm).  HM_GEMM_VARIANT / hm_gemm_set_variant select one
 // for tuning runs; the default is chosen per shape in pick_variant().
+int g_group_m = 8;
 int g_variant = -2;    // -2: read HM_GEMM_VARIANT on first use; -1: per-shape default
 
 template <class T, int EPI>
@@ -281,6 +486,12 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 13: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 91>(g, s, "hm_gemm"); // ABLATION (wrong results): no MFMA
     case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // ABLATION: LDS-DMA + waits + barriers only
     case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ABLATION: ds_read + MFMA + barriers, no loads
+    case 18: return launch_pipe<T, EPI, 4, 2, 4, 8>(g, s);                             // 256x256x32 ring of 4, fragments double-buffered
+    case 19: return launch_pipe<T, EPI, 2, 4, 8, 4>(g, s);                             // same, waves 2x4 (128x64 each)
+    case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // ABLATION: no epilogue
+    case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
+    case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
+    case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
     case 16: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 94>(g, s, "hm_gemm"); // EXPERIMENT: fill only, tile-major operands
     case 17: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 95>(g, s, "hm_gemm"); // EXPERIMENT: full kernel, tile-major operands
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
@@ -333,8 +544,14 @@ int launch_conv(const KArgs& g, int epilogue, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int hm_gemm_set_group_m(int gm) {
+  if (gm < 1 || gm > 64) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_group_m: 1..64");
+  g_group_m = gm;
+  return HM_OK;
+}
+
 extern "C" int hm_gemm_set_variant(int v) {
-  if (v < -1 || v > 17) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) .. 15 (12..15: timing ablations)");
+  if (v < -1 || v > 23) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) .. 15 (12..15: timing ablations)");
   g_variant = v;
   return HM_OK;
 }
@@ -356,6 +573,7 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
   KArgs k{};
   k.X = g.X; k.W = g.W; k.C = g.C; k.bias = g.bias; k.resid = g.resid;
   k.M = g.M; k.N = g.N; k.K = g.K; k.ldx = g.ldx; k.ldw = g.ldw; k.ldc = g.ldc; k.ldr = g.ldr; k.resid_mod = g.resid_mod;
+  k.group_m = g_group_m;
   HmProfScope prof(HM_K_GEMM, g.epilogue, g.M, g.N, g.K, stream);
   if (g.dtype == HM_DTYPE_BF16) return launch_gemm_epi<TBf16>(k, g.epilogue, stream);
   if (g.dtype == HM_DTYPE_F16) return launch_gemm_epi<TF16>(k, g.epilogue, stream);
@@ -385,7 +603,7 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   k.X = c.X; k.W = c.W; k.C = c.Y; k.bias = c.bias; k.resid = nullptr;
   k.M = c.N * Hout * Wout; k.N = c.Cout; k.K = c.Kpad; k.ldx = c.ldx; k.ldw = c.Kpad; k.ldc = c.ldy; k.ldr = 0; k.resid_mod = 0;
   k.zeros = c.zeros; k.H = c.H; k.Wd = c.W_in; k.Hout = Hout; k.Wout = Wout; k.ksz = c.ksize; k.stride = c.stride; k.pad = pad;
-  k.cin_log2 = lg; k.taps = taps;
+  k.cin_log2 = lg; k.taps = taps; k.group_m = g_group_m;
   if (c.out_f32 && c.act) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: f32 output has no activation");
   const int epi = c.out_f32 ? HM_EPI_F32 : (c.act ? HM_EPI_SILU : HM_EPI_STORE);
   HmProfScope prof(HM_K_CONV, c.ksize * 10 + c.stride, k.M, k.N, ktrue, stream);

@@ -20,7 +20,7 @@ EXPORTS = [
     "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
-    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant",
+    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -137,6 +137,7 @@ def load() -> C.CDLL:
     lib.hm_yolo_nms.argtypes = [vp, i, i, f, f, C.c_uint, i, i, C.POINTER(LetterboxPlan), vp, vp, vp, C.c_size_t, vp]
     lib.hm_yolo_run.argtypes = [C.POINTER(YoloOp), i, vp]
     lib.hm_gemm_set_variant.argtypes = [i]
+    lib.hm_gemm_set_group_m.argtypes = [i]
     lib.hm_prof_begin.argtypes = [i]
     lib.hm_prof_collect.argtypes = [C.POINTER(ProfRecord), i]
     lib.hm_prof_end.argtypes = []

@@ -58,6 +58,8 @@ int hm_gemm(const hm_gemm_args* args, void* stream);
  * (also settable through the HM_GEMM_VARIANT environment variable).  Results do not depend on it
  * beyond fp32 summation order. */
 int hm_gemm_set_variant(int variant);
+/* Tuning hook: M-tiles per group in the XCD-aware tile walk (default 8). */
+int hm_gemm_set_group_m(int group_m);
 
 /* nn.LayerNorm over the last dim (vit.py:136,:144,:252 eps 1e-6; t_cond_mlp.py:51-52 eps 1e-5).
  * x [M][D] f32 -> out [M][D]; out_dtype: HM_DTYPE_BF16 / HM_DTYPE_F16 / HM_OUT_F32. */

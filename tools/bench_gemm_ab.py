@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamer_yolo_amd import lib as L
 from hamer_yolo_amd import ops
 
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,8").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,8").split(",")]      # v >= 100: default variant with group_m = v - 100
 rounds, reps = int(os.environ.get("ROUNDS", 6)), int(os.environ.get("REPS", 5))
 M = int(os.environ.get("BATCH", 64)) * 192
 dev = "cuda"
@@ -20,6 +20,15 @@ shapes = [("qkv", 1280, 3840, L.HM_EPI_STORE), ("proj", 1280, 1280, L.HM_EPI_RES
           ("fc2", 5120, 1280, L.HM_EPI_RESID_F32)]
 lib = L.load()
 res = {}
+
+
+def setv(v):
+    if v >= 100:
+        L.check(lib.hm_gemm_set_variant(-1)); L.check(lib.hm_gemm_set_group_m(v - 100))
+    else:
+        L.check(lib.hm_gemm_set_variant(v)); L.check(lib.hm_gemm_set_group_m(8))
+
+
 for (name, K, N, epi) in shapes:
     x = torch.randn(M, K, device=dev).bfloat16()
     w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
@@ -29,11 +38,11 @@ for (name, K, N, epi) in shapes:
     r = torch.randn(M, N, device=dev) if f32 else None
     times = {v: [] for v in variants}
     for v in variants:                        # warm
-        L.check(lib.hm_gemm_set_variant(v)); ops.gemm(x, w, b, epi, resid=r, out=out)
+        setv(v); ops.gemm(x, w, b, epi, resid=r, out=out)
     torch.cuda.synchronize()
     for _ in range(rounds):
         for v in variants:
-            L.check(lib.hm_gemm_set_variant(v))
+            setv(v)
             with L.profile(capacity=reps + 2) as prof:
                 for _ in range(reps):
                     ops.gemm(x, w, b, epi, resid=r, out=out)

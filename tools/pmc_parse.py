@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Parse rocprofv3 --pmc CSVs of tools/pmc_shapes.py into per-launch HBM traffic (bytes).
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
+stream, so it is doubled (MI355X_MICROARCH.md, HBM section)."""
+import csv
+import json
+import sys
+
+sys.path.insert(0, "tools")
+from pmc_shapes import SHAPES, M  # noqa: E402
+
+def per_kernel(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    ours = [r for r in rows if any(k in r["Kernel_Name"] for k in ("gemm_tn_kernel", "gemm_pipe_kernel", "layernorm_kernel", "vit_attention_kernel"))]
+    return [float(r["Counter_Value"]) for r in ours]
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+names = [s[0] for s in SHAPES] + ["layernorm", "attention"]
+n = len(names)
+assert len(fetch) == 2 * n and len(write) == 2 * n, (len(fetch), len(write))
+out = {}
+for i, nm in enumerate(names):
+    f = fetch[n + i] * 1024 * 2      # second repetition; gfx950 correction x2
+    w = write[n + i] * 1024
+    alg = None
+    if i < len(SHAPES):
+        _, K, N, epi = SHAPES[i]
+        osz = 4 if epi == 2 else 2
+        alg = M * K * 2 + N * K * 2 + M * N * osz + (M * N * 4 if epi == 2 else 0)
+    out[nm] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w, "algorithmic_bytes": alg}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
