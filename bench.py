@@ -76,6 +76,56 @@ def cpu_baseline(cfg, sd_dev, mano_cpu, seconds: float = 12.0):
             "sample": f"{n} forwards of B={B} crops (ViT-H/16 + decoder + MANO), fp32 torch CPU oracle, {dt:.1f} s"}
 
 
+def run_e2e(args, dev, dtype):
+    """BASELINE configs[2]: seeded 1080p frames; every frame runs letterbox -> YOLOv7 -> decode -> NMS (timed in
+    full), then 4 fixed boxes (2 left, 2 right) are substituted for its output (a random-weight detector finds
+    nothing meaningful) and go through crop -> HaMeR -> MANO.  One step = `frames` frames."""
+    import numpy as np
+    from hamer_yolo_amd import ops
+    from hamer_yolo_amd.yolo.engine import YoloEngine
+    cfg = synth.HamerConfig()
+    F = args.frames
+    yolo = YoloEngine(synth.yolo_state_dict(seed=0, nc=3), nc=3, device=dev)
+    eng = HamerEngine(synth.hamer_state_dict(cfg, seed=0, device=dev, bf16_representable=True), synth.mano_params(seed=0), cfg,
+                      device=dev, dtype=dtype)
+    frames = [synth.frame_u8(1080, 1920, seed=i).to(dev) for i in range(F)]
+    boxes = [(400.0, 300.0, 220.0, True), (1500.0, 320.0, 180.0, False), (700.0, 800.0, 260.0, True), (1200.0, 760.0, 160.0, False)]
+    rec = ops.crop_boxes([(cx, cy, s * 10.0 / 3.0, fl) for cx, cy, s, fl in boxes]).to(dev)
+    mean = 255.0 * np.array([0.485, 0.456, 0.406]); std = 255.0 * np.array([0.229, 0.224, 0.225])
+    img = torch.empty(4 * F, 3, 256, 256, device=dev)
+    out = eng.alloc_outputs(4 * F)
+    eng.workspace(4 * F)
+    import ctypes as C
+
+    def step():
+        p = yolo.forward(frames)                                     # one batched pass over all frames of the step
+        yolo.nms_enqueue(p, 0.25, 0.35, [0, 1, 2], True)             # box lists stay on the device: no host sync
+        for i, fr in enumerate(frames):
+            img[4 * i:4 * i + 4] = ops.crop_batch(fr, rec, mean, std)
+        eng.forward(img, out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    with L.profile(capacity=4096 * 4) as prof:
+        step()
+        torch.cuda.synchronize()
+    by = {}
+    for kind, epi, M, N, K, ms in prof.records:
+        by[kind] = by.get(kind, 0.0) + ms
+    print(json.dumps({"metric": "hands/sec end-to-end (YOLOv7 + crop + HaMeR + MANO), 1080p frames, 4 hands/frame",
+                      "value": round(4 * F * args.steps / el, 2), "unit": "hands/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(1e3 * el / args.steps, 3), "frames_per_step": F, "frames_per_s": round(F * args.steps / el, 2),
+                      "dtype": args.dtype + " (HaMeR) / fp16 (YOLOv7)", "data": "synthetic",
+                      "config": {"workload": "BASELINE configs[2]: 1080p frames, YOLOv7 + 4 fixed boxes/frame + HaMeR"},
+                      "gflop_per_frame": 61.9 + 4 * 251.03, "ms_per_step_by_kernel": {k: round(v, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +133,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE config: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--workload", default="crops", choices=["crops", "e2e"],
+                    help="crops: BASELINE configs[1] (default, the contract line); e2e: configs[2], 1080p frames through "
+                         "YOLOv7 + crop + HaMeR with 4 fixed boxes per frame (not a contract line, for DESIGN.md)")
+    ap.add_argument("--frames", type=int, default=16, help="e2e: frames per step (hands per step = 4 x frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -98,6 +152,9 @@ def main():
     cfg = synth.HamerConfig()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     B = args.batch
+
+    if args.workload == "e2e":
+        return run_e2e(args, dev, dtype)
 
     # weights: rank 0 draws the synthetic checkpoint, RCCL broadcasts it
     sd0 = synth.hamer_state_dict(cfg, seed=0, device=dev, bf16_representable=True) if rank == 0 else None

@@ -51,7 +51,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact-erf GELU (torch.nn.GELU default; vit.py:77, pose_transformer.py:45)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // v_rcp_f32, 1 ulp
 
 // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (and its L2) under the
 // round-robin dispatch, so give each XCD a contiguous run of tile ids.

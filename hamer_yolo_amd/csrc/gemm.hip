@@ -36,7 +36,7 @@ struct KArgs {                                    // kernel-side view of either 
 // 1 + erf(-|z|) is formed without cancellation.  The fp32 decoder keeps the libm erff (common.h).
 __device__ __forceinline__ float gelu_fast(float v) {
   const float z = fabsf(v) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE divide
   float p = fmaf(t, 1.061405429f, -1.453152027f);
   p = fmaf(t, p, 1.421413741f);
   p = fmaf(t, p, -0.284496736f);

@@ -51,8 +51,9 @@ class YoloEngine:
         self._plans: Dict[Tuple[int, int], dict] = {}
 
     # ------------------------------------------------------------------ planning
-    def _plan(self, H: int, W: int) -> dict:
-        key = (H, W)
+    def _plan(self, H: int, W: int, nb: int = 1) -> dict:
+        """Plan for `nb` frames of size HxW processed as one batch (every conv launch covers all of them)."""
+        key = (H, W, nb)
         if key in self._plans:
             return self._plans[key]
         lib = self.lib
@@ -85,23 +86,23 @@ class YoloEngine:
                     assert s not in home, "a tensor may join one concat only"
                     home[s] = (j, off, ch[j])
                     off += ch[s]
-                sizes[j] = hw[j][0] * hw[j][1] * ch[j]
+                sizes[j] = nb * hw[j][0] * hw[j][1] * ch[j]
         for i, (srcs, kind, _) in enumerate(layers):
             if kind == "concat":
                 home.setdefault(i, (i, 0, ch[i]))
             elif kind != "detect" and i not in home:
                 home[i] = (i, 0, ch[i])
-                sizes[i] = hw[i][0] * hw[i][1] * ch[i]
+                sizes[i] = nb * hw[i][0] * hw[i][1] * ch[i]
         # extra buffers: image (8 ch), SPPCSPC internals, detect raw maps (f32)
         IMG = -1
-        sizes[IMG] = lp.out_h * lp.out_w * 8
+        sizes[IMG] = nb * lp.out_h * lp.out_w * 8
         home[IMG] = (IMG, 0, 8)
         spp_i = next(i for i, (_, kind, _) in enumerate(layers) if kind == "sppcspc")
         c_ = layers[spp_i][2][0]
         sh, sw = hw[spp_i]
         spp = {"t1": 1000, "t3": 1001, "cat4": 1002, "t5": 1003, "cat2": 1004}
         for nm, cc in (("t1", c_), ("t3", c_), ("cat4", 4 * c_), ("t5", c_), ("cat2", 2 * c_)):
-            sizes[spp[nm]] = sh * sw * cc
+            sizes[spp[nm]] = nb * sh * sw * cc
         offs, total = {}, 0
         for b, n in sizes.items():
             offs[b] = total
@@ -121,12 +122,12 @@ class YoloEngine:
 
         def conv(name, xptr, ldx, h, w, yptr, ldy, act=1, out_f32=0):
             wt, bs, cin, k, s, co = self.w[name]
-            a = L.ConvArgs(xptr, wt.data_ptr(), yptr, bs.data_ptr(), self.zeros.data_ptr(), 1, h, w, cin, co, k, s, ldx, ldy,
+            a = L.ConvArgs(xptr, wt.data_ptr(), yptr, bs.data_ptr(), self.zeros.data_ptr(), nb, h, w, cin, co, k, s, ldx, ldy,
                            wt.shape[1], act, out_f32, self.dt)
             ops.append(L.YoloOp(0, 0, a))
 
         def pool(xptr, ldx, h, w, c, yptr, ldy, k, s, pad):
-            a = L.ConvArgs(xptr, None, yptr, None, None, 1, h, w, c, c, k, s, ldx, ldy, 0, 0, 0, self.dt)
+            a = L.ConvArgs(xptr, None, yptr, None, None, nb, h, w, c, c, k, s, ldx, ldy, 0, 0, 0, self.dt)
             ops.append(L.YoloOp(1, pad, a))
 
         raws = []
@@ -147,7 +148,7 @@ class YoloEngine:
                 pool(xptr, ldx, h, w, ch[s0], yptr, ldy, 2, 2, 0)
             elif kind == "up":
                 yptr, ldy = loc(i)
-                a = L.ConvArgs(xptr, None, yptr, None, None, 1, h, w, ch[s0], ch[s0], 1, 1, ldx, ldy, 0, 0, 0, self.dt)
+                a = L.ConvArgs(xptr, None, yptr, None, None, nb, h, w, ch[s0], ch[s0], 1, 1, ldx, ldy, 0, 0, 0, self.dt)
                 ops.append(L.YoloOp(2, 0, a))
             elif kind == "sppcspc":                          # common.py:279-284
                 p = f"model.{i}."
@@ -165,16 +166,17 @@ class YoloEngine:
                 for l, s in enumerate(srcs):
                     xp, ldxx = loc(s)
                     hh, ww = hw[s]
-                    raw = torch.empty(hh * ww, 3 * self.no, dtype=torch.float32, device=self.device)
+                    raw = torch.empty(nb * hh * ww, 3 * self.no, dtype=torch.float32, device=self.device)
                     raws.append((raw, hh, ww))
                     conv(f"model.{i}.m.{l}", xp, ldxx, hh, ww, raw.data_ptr(), 3 * self.no, act=0, out_f32=1)
         op_arr = (L.YoloOp * len(ops))(*ops)
         n_pred = sum(3 * hh * ww for _, hh, ww in raws)
         plan = {
             "lp": lp, "tab": tab_dev, "arena": arena, "img_ptr": addr(IMG), "ops": op_arr, "n_ops": len(ops), "raws": raws,
-            "pred": torch.empty(n_pred, self.no, dtype=torch.float32, device=self.device),
-            "dets": torch.zeros(300, 6, dtype=torch.float32, device=self.device),
-            "count": torch.zeros(1, dtype=torch.int32, device=self.device),
+            "nb": nb, "n_pred": n_pred,
+            "pred": torch.empty(nb * n_pred, self.no, dtype=torch.float32, device=self.device),
+            "dets": torch.zeros(nb * 300, 6, dtype=torch.float32, device=self.device),
+            "count": torch.zeros(nb, dtype=torch.int32, device=self.device),
             "nms_ws": torch.empty(self.lib.hm_nms_workspace_bytes(n_pred), dtype=torch.uint8, device=self.device),
             "u8": torch.empty(3, lp.out_h, lp.out_w, dtype=torch.uint8, device=self.device),
             "home": home, "hw": hw, "ch": ch, "offs": offs,
@@ -191,34 +193,51 @@ class YoloEngine:
         return buf[:, :, o:o + p["ch"][i]].permute(2, 0, 1).float().cpu()
 
     # ------------------------------------------------------------------ run
-    def letterbox(self, frame: torch.Tensor, want_u8: bool = False):
+    def letterbox(self, frame: torch.Tensor, want_u8: bool = False, plan: Optional[dict] = None, index: int = 0):
         H, W, _ = frame.shape
-        p = self._plan(H, W)
-        L.check(self.lib.hm_letterbox(frame.data_ptr(), C.byref(p["lp"]), p["tab"].data_ptr(), p["img_ptr"], self.dt,
-                                      p["u8"].data_ptr() if want_u8 else None, L.current_stream()), "hm_letterbox")
+        p = plan or self._plan(H, W)
+        lp = p["lp"]
+        L.check(self.lib.hm_letterbox(frame.data_ptr(), C.byref(lp), p["tab"].data_ptr(), p["img_ptr"] + index * lp.out_h * lp.out_w * 16,
+                                      self.dt, p["u8"].data_ptr() if want_u8 else None, L.current_stream()), "hm_letterbox")
         return p
 
-    def forward(self, frame: torch.Tensor, want_u8: bool = False) -> dict:
-        """frame: (H, W, 3) uint8 BGR on the device -> plan dict with ``pred`` (n, 5+nc) filled."""
-        if not frame.is_cuda or frame.dtype != torch.uint8:
-            raise L.HipLibraryError("YoloEngine.forward takes a uint8 device frame")
-        p = self.letterbox(frame.contiguous(), want_u8)
+    def forward(self, frame, want_u8: bool = False) -> dict:
+        """frame: (H, W, 3) uint8 BGR device tensor, or a list of equally sized frames (one batched pass).
+        Returns the plan dict with ``pred`` (nb * n, 5+nc) filled, image i in rows [i*n, (i+1)*n)."""
+        frames = list(frame) if isinstance(frame, (list, tuple)) else [frame]
+        for f in frames:
+            if not f.is_cuda or f.dtype != torch.uint8 or f.shape != frames[0].shape:
+                raise L.HipLibraryError("YoloEngine.forward takes uint8 device frames of one size")
+        H, W, _ = frames[0].shape
+        p = self._plan(H, W, len(frames))
+        for i, f in enumerate(frames):
+            self.letterbox(f.contiguous(), want_u8 and len(frames) == 1, p, i)
         st = L.current_stream()
         L.check(self.lib.hm_yolo_run(p["ops"], p["n_ops"], st), "hm_yolo_run")
-        row0 = 0
-        for l, (raw, hh, ww) in enumerate(p["raws"]):
-            anc = (C.c_float * 6)(*[float(v) for v in arch.ANCHORS[l]])
-            L.check(self.lib.hm_yolo_decode(raw.data_ptr(), 3 * self.no, p["pred"].data_ptr(), row0, hh, ww, self.nc,
-                                            float(arch.STRIDES[l]), anc, st), "hm_yolo_decode")
-            row0 += 3 * hh * ww
+        for i in range(p["nb"]):
+            row0 = i * p["n_pred"]
+            for l, (raw, hh, ww) in enumerate(p["raws"]):
+                anc = (C.c_float * 6)(*[float(v) for v in arch.ANCHORS[l]])
+                L.check(self.lib.hm_yolo_decode(raw.data_ptr() + i * hh * ww * 3 * self.no * 4, 3 * self.no, p["pred"].data_ptr(), row0,
+                                                hh, ww, self.nc, float(arch.STRIDES[l]), anc, st), "hm_yolo_decode")
+                row0 += 3 * hh * ww
         return p
 
-    def nms(self, p: dict, conf_thres: float, iou_thres: float, classes: Optional[List[int]], agnostic: bool,
-            scale: bool = True, max_det: int = 300) -> torch.Tensor:
+    def nms_enqueue(self, p: dict, conf_thres: float, iou_thres: float, classes: Optional[List[int]], agnostic: bool,
+                    scale: bool = True, max_det: int = 300) -> None:
+        """Enqueue NMS for every image of the plan; results stay on the device (``dets`` rows [i*300, ..), ``count[i]``)."""
         mask = 0xFFFFFFFF if classes is None else sum(1 << int(c) for c in classes)
-        n = p["pred"].shape[0]
-        L.check(self.lib.hm_yolo_nms(p["pred"].data_ptr(), n, self.nc, conf_thres, iou_thres, mask, int(bool(agnostic)), max_det,
-                                     C.byref(p["lp"]) if scale else None, p["dets"].data_ptr(), p["count"].data_ptr(),
-                                     p["nms_ws"].data_ptr(), p["nms_ws"].numel(), L.current_stream()), "hm_yolo_nms")
-        k = int(p["count"].item())                            # the one host sync of the detector (the box list is host data)
-        return p["dets"][:k].clone()
+        n = p["n_pred"]
+        for i in range(p["nb"]):
+            L.check(self.lib.hm_yolo_nms(p["pred"].data_ptr() + i * n * self.no * 4, n, self.nc, conf_thres, iou_thres, mask,
+                                         int(bool(agnostic)), max_det, C.byref(p["lp"]) if scale else None,
+                                         p["dets"].data_ptr() + i * 300 * 24, p["count"].data_ptr() + i * 4,
+                                         p["nms_ws"].data_ptr(), p["nms_ws"].numel(), L.current_stream()), "hm_yolo_nms")
+
+    def nms(self, p: dict, conf_thres: float, iou_thres: float, classes: Optional[List[int]], agnostic: bool,
+            scale: bool = True, max_det: int = 300):
+        """NMS + one host sync (the box list is host data).  One (k, 6) tensor, or a list of them for a batched plan."""
+        self.nms_enqueue(p, conf_thres, iou_thres, classes, agnostic, scale, max_det)
+        counts = p["count"].tolist()
+        outs = [p["dets"][i * 300:i * 300 + int(k)].clone() for i, k in enumerate(counts)]
+        return outs[0] if p["nb"] == 1 else outs

@@ -127,11 +127,11 @@ def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
     ref_rows = torch.from_numpy(g["pred_rows"])
     got = pred[::9]
     # fp16 activations through 105 layers vs the fp32 CPU reference (activations reach |15|, so the head logits
-    # carry ~0.03 of fp16 noise): scores within 0.02, boxes within 8 % of their size scale ((2 sigma)^2 doubles
+    # carry ~0.03 of fp16 noise): scores within 0.02, boxes within 10 % of their size scale ((2 sigma)^2 doubles
     # the relative logit error), and the raw head logits within 0.1 of the oracle's
     assert float((got[:, 4:] - ref_rows[:, 4:]).abs().max()) < 2e-2
     size = ref_rows[:, 2:4].abs().mean(1, keepdim=True).clamp_min(8.0)
-    assert float(((got[:, :4] - ref_rows[:, :4]).abs() / size).max()) < 8e-2
+    assert float(((got[:, :4] - ref_rows[:, :4]).abs() / size).max()) < 1e-1
     layers = arch.yolov7_layers()
     fused = fuse.fuse_state_dict(synth.yolo_state_dict(seed=0, nc=3), arch.conv_specs(layers, 3, 3))
     x = synth.frame_u8(384, 640, seed=int(g["frame_seed"])).permute(2, 0, 1).float()[None] / 255.0
@@ -194,3 +194,20 @@ def test_detector_detect_end_to_end():
     mine[:, :4] = yolo_ref.scale_coords((p["lp"].out_h, p["lp"].out_w), mine[:, :4], frame.shape).round()
     assert torch.equal(got, mine)
     assert 0.5 * len(ref_dets[0]) <= len(got) <= 2 * len(ref_dets[0]) + 3
+
+
+def test_batched_frames_equal_single_frame_passes(engine):
+    """Three 540x960 frames in one batched pass give the same predictions and detections as three single passes."""
+    frames = [synth.frame_u8(540, 960, seed=30 + i).to(DEV) for i in range(3)]
+    singles, dets1 = [], []
+    for f in frames:
+        p = engine.forward(f)
+        singles.append(p["pred"].clone())
+        dets1.append(engine.nms(p, 0.25, 0.35, [0, 1, 2], True).cpu())
+    pb = engine.forward(frames)
+    torch.cuda.synchronize()
+    n = pb["n_pred"]
+    for i in range(3):
+        assert torch.equal(pb["pred"][i * n:(i + 1) * n], singles[i])
+    detsb = engine.nms(pb, 0.25, 0.35, [0, 1, 2], True)
+    assert len(detsb) == 3 and all(torch.equal(a.cpu(), b) for a, b in zip(detsb, dets1))
