@@ -230,9 +230,20 @@ def main():
                 e[0] += 1; e[1] += ms; e[2] += 2.0 * M * N * K
         n_gemm = sum(v[0] for v in per.values())
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        # HBM-side bytes per GEMM launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # runs over tools/pmc_shapes.py, gfx950 FETCH_SIZE x2 correction; tools/pmc_parse.py), weighted by launches per step
+        traffic, traffic_src = None, os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(traffic_src) and B == 64:
+            t = json.load(open(traffic_src))
+            w = {"patch": 1, "qkv": cfg.vit.depth, "proj": cfg.vit.depth, "fc1": cfg.vit.depth, "fc2": cfg.vit.depth, "kv": 1}
+            traffic = round(sum(t[k]["hbm_bytes"] * n for k, n in w.items()) / sum(w.values()))
         res["roofline"] = {
             "kernel": "gemm_tn_kernel (all epilogues)", "bound": "mfma", "achieved": round(achieved, 2),
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": "bytes per launch beyond L2 (FETCH_SIZE*2 + WRITE_SIZE, PMC pass committed under profiles/; Infinity-Cache hits included), "
+                            "algorithmic operand+result bytes per launch: %d" % round(sum(
+                                (2 * (M_ * K_ + N_ * K_) + M_ * N_ * (8 if e_ == 2 else 2)) for (_, e_, M_, N_, K_, _) in
+                                [r for r in prof.records if r[0] == "gemm"]) / n_gemm),
             "launches_per_step": n_gemm // nprof, "avg_launch_ms": round(gemm_ms / n_gemm, 5),
             "flop_per_launch": round(gemm_fl / n_gemm),
             "per_epilogue": {k: {"launches_per_step": v[0] // nprof, "avg_ms": round(v[1] / v[0], 5),

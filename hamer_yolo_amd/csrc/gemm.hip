@@ -125,31 +125,68 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
       }
     if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // LDS -> row-major, bias / activation / residual, coalesced stores
+    if constexpr ((EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU) && NCH >= 8) {
+      // 16-bit outputs: 8 columns (two staged chunks) per lane -> one 16-byte store, NCH/2 lanes per row
+      constexpr int LPR = NCH / 2, RPI2 = 64 / LPR, ITS2 = MI * 16 / RPI2;
+      const int row0 = lane / LPR, j = lane % LPR;
 #pragma unroll 2
-    for (int it = 0; it < ITS; ++it) {
-      const int row = it * RPI + rrow, m = mb + row;
-      const int n = ncol0 + ((rslot ^ (row & (NCH - 1))) << 2);
-      f32x4_t v = *(const f32x4_t*)(wlds + row * RS + rslot * 16);
-      f32x4_t r = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (RES) r = *(const f32x4_t*)(rlds + row * RS + rslot * 16);
-      if (m >= g.M || n >= g.N) continue;
-      if (bias) v += *(const f32x4_t*)(bias + n);
-      if (EPI == HM_EPI_GELU) {
+      for (int it = 0; it < ITS2; ++it) {
+        const int row = it * RPI2 + row0, m = mb + row, n = ncol0 + 8 * j;
+        const int sw = row & (NCH - 1);
+        f32x4_t v0 = *(const f32x4_t*)(wlds + row * RS + ((2 * j) ^ sw) * 16);
+        f32x4_t v1 = *(const f32x4_t*)(wlds + row * RS + ((2 * j + 1) ^ sw) * 16);
+        if (m >= g.M || n >= g.N) continue;
+        if (bias) { v0 += *(const f32x4_t*)(bias + n); v1 += *(const f32x4_t*)(bias + n + 4); }
+        typename T::vec8 o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
-      } else if (EPI == HM_EPI_SILU) {
+        for (int q = 0; q < 4; ++q) {
+          float a = v0[q], b = v1[q];
+          if (EPI == HM_EPI_GELU) { a = gelu_fast(a); b = gelu_fast(b); }
+          else if (EPI == HM_EPI_SILU) { a = silu(a); b = silu(b); }
+          o[q] = (elem)a; o[4 + q] = (elem)b;
+        }
+        if (n + 8 <= g.N && (g.ldc & 7) == 0) {
+          *(typename T::vec8*)((elem*)g.C + (size_t)m * g.ldc + n) = o;
+        } else if (n + 8 <= g.N) {                   // rows not 16-byte aligned: two 8-byte stores
+          typename T::vec4 h0, h1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+          for (int q = 0; q < 4; ++q) { h0[q] = o[q]; h1[q] = o[4 + q]; }
+          *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n) = h0;
+          *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n + 4) = h1;
+        } else {                                     // ragged N (N % 8 == 4): first half only
+          typename T::vec4 h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) h[q] = o[q];
+          *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n) = h;
+        }
       }
-      if (RES) {
-        *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v + r;
-      } else if (EPI == HM_EPI_F32) {
-        *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v;
-      } else {
-        typename T::vec4 o;
+    } else {
+#pragma unroll 2
+      for (int it = 0; it < ITS; ++it) {
+        const int row = it * RPI + rrow, m = mb + row;
+        const int n = ncol0 + ((rslot ^ (row & (NCH - 1))) << 2);
+        f32x4_t v = *(const f32x4_t*)(wlds + row * RS + rslot * 16);
+        f32x4_t r = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (RES) r = *(const f32x4_t*)(rlds + row * RS + rslot * 16);
+        if (m >= g.M || n >= g.N) continue;
+        if (bias) v += *(const f32x4_t*)(bias + n);
+        if (EPI == HM_EPI_GELU) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = (elem)v[q];
-        *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n) = o;
+          for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
+        } else if (EPI == HM_EPI_SILU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+        }
+        if (RES) {
+          *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v + r;
+        } else if (EPI == HM_EPI_F32) {
+          *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v;
+        } else {
+          typename T::vec4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (elem)v[q];
+          *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n) = o;
+        }
       }
     }
   }
