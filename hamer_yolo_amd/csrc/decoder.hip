@@ -27,7 +27,19 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
   const float* xp = x + (size_t)mr * ldx + 4 * g;
   const float* wp = W + (size_t)nr * ldw + 4 * g;
   f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  for (int kb = wave * 16; kb < K; kb += 64) {
+  // the loop is latency-bound (few waves, dependent MFMA chain): fetch 4 k-blocks ahead so 8 loads are in flight
+  constexpr int PF = 4;
+  int kb = wave * 16;
+  for (; kb + 64 * (PF - 1) < K; kb += 64 * PF) {
+    f32x4_t xv[PF], wv[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) { xv[p] = *(const f32x4_t*)(xp + kb + 64 * p); wv[p] = *(const f32x4_t*)(wp + kb + 64 * p); }
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[p][i], xv[p][i], acc, 0, 0, 0);
+  }
+  for (; kb < K; kb += 64) {
     const f32x4_t xv = *(const f32x4_t*)(xp + kb);
     const f32x4_t wv = *(const f32x4_t*)(wp + kb);
 #pragma unroll
