@@ -137,6 +137,7 @@ def main():
                     help="crops: BASELINE configs[1] (default, the contract line); e2e: configs[2], 1080p frames through "
                          "YOLOv7 + crop + HaMeR with 4 fixed boxes per frame (not a contract line, for DESIGN.md)")
     ap.add_argument("--frames", type=int, default=16, help="e2e: frames per step (hands per step = 4 x frames)")
+    ap.add_argument("--split", type=int, default=-1, help="1/0: force the two-stream half-batch schedule on/off (default: engine's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -172,8 +173,10 @@ def main():
     out = eng.alloc_outputs(B)
     eng.workspace(B)
 
+    split = None if args.split < 0 else bool(args.split)
+
     def step():
-        eng.forward(img, out)
+        eng.forward(img, out, split=split)
         if world > 1:
             shard.gather_mano(shard.pack_mano(out), dst=0)
 
@@ -218,7 +221,7 @@ def main():
         nprof = min(args.steps, 5)
         with L.profile(capacity=nprof * 512) as prof:
             for _ in range(nprof):
-                eng.forward(img, out)
+                eng.forward(img, out, split=False)      # one stream: every launch timed alone, nothing overlapping it
             torch.cuda.synchronize()
         by_kind, gemm_fl, gemm_ms, per = {}, 0.0, 0.0, {}
         for kind, epi, M, N, K, ms in prof.records:
