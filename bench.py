@@ -28,7 +28,7 @@ from hamer_yolo_amd import shard, synth  # noqa: E402
 from hamer_yolo_amd.engine import HamerEngine  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-EPI_NAMES = {0: "store", 1: "gelu", 2: "resid_f32", 3: "f32", 4: "silu"}
+EPI_NAMES = {0: "store", 1: "gelu", 2: "resid_f32", 3: "f32", 4: "silu", 5: "resid_ln", 6: "ln_store", 7: "ln_gelu"}
 
 
 def flops_per_hand(cfg: synth.HamerConfig) -> dict:
@@ -245,7 +245,7 @@ def main():
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_note": "bytes per launch beyond L2 (FETCH_SIZE*2 + WRITE_SIZE, PMC pass committed under profiles/; Infinity-Cache hits included), "
                             "algorithmic operand+result bytes per launch: %d" % round(sum(
-                                (2 * (M_ * K_ + N_ * K_) + M_ * N_ * (8 if e_ == 2 else 2)) for (_, e_, M_, N_, K_, _) in
+                                (2 * (M_ * K_ + N_ * K_) + M_ * N_ * {2: 8, 5: 10}.get(e_, 2)) for (_, e_, M_, N_, K_, _) in
                                 [r for r in prof.records if r[0] == "gemm"]) / n_gemm),
             "launches_per_step": n_gemm // nprof, "avg_launch_ms": round(gemm_ms / n_gemm, 5),
             "flop_per_launch": round(gemm_fl / n_gemm),

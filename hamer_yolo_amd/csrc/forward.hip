@@ -11,7 +11,7 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, total;
+  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, total;
 };
 
 Layout make_layout(const hm_hamer_weights& w, int B) {
@@ -33,6 +33,8 @@ Layout make_layout(const hm_hamer_weights& w, int B) {
   L.t1 = o; o += align256((size_t)B * (inner > dmax ? inner : dmax) * 4);
   L.t2 = o; o += align256((size_t)B * (inner > dmax ? inner : dmax) * 4);
   L.head = o; o += align256((size_t)B * 112 * 4);
+  L.stats = o; o += align256(M * ((D + 63) / 64) * 8);      // deferred-LN partials [D/64][M][2]
+  L.rowstats = o; o += align256(M * 8);                      // (mean, rstd) per row
   L.total = o;
   return L;
 }
@@ -73,28 +75,50 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
   float* x = (float*)(ws + L.x);
   void *h = ws + L.h, *qkv = ws + L.qkv, *att = ws + L.att, *mlp = ws + L.mlp, *kv = ws + L.kv;
 
+  float *stats = (float*)(ws + L.stats), *rowstats = (float*)(ws + L.rowstats);
+  // deferred LayerNorm (hm_gemm HM_EPI_RESID_LN / HM_EPI_LN_*): `ln` = gamma of the next LayerNorm for a GEMM that
+  // writes x, or the folded column sums for a GEMM that reads LN(x); `h` then holds x * gamma instead of LN(x)
   auto gemm = [&](const void* X, int ldx, const void* W, int K, int N, void* C, int ldc, const float* bias, int epi,
-                  const float* resid, int ldr, int rmod) {
-    hm_gemm_args g;
+                  const float* resid, int ldr, int rmod, const float* ln = nullptr) {
+    hm_gemm_args g{};
     g.X = X; g.W = W; g.C = C; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldw = K; g.ldc = ldc; g.ldr = ldr; g.resid_mod = rmod;
     g.epilogue = epi; g.dtype = dt;
-    return hm_gemm(&g, stream);
+    if (epi == HM_EPI_RESID_LN) { g.ln_gamma = ln; g.ln_xg = h; g.ln_stats = stats; }
+    if (epi == HM_EPI_LN_STORE || epi == HM_EPI_LN_GELU) { g.ln_colsum = ln; g.ln_stats = rowstats; }
+    HM_TRY(hm_gemm(&g, stream));
+    if (epi == HM_EPI_RESID_LN) return hm_ln_finalize(stats, rowstats, M, N, w->vit_eps, stream);
+    return HM_OK;
   };
+  bool fold = D % 64 == 0 && w->depth > 0;
+  for (int i = 0; i < w->depth && fold; ++i) {
+    const hm_vit_block& b = w->blocks[i];
+    fold = b.qkv_colsum && b.qkv_bias_ln && b.fc1_colsum && b.fc1_bias_ln;
+  }
 
   // ---- ViT backbone (vit.py:320-339)
   HM_TRY(hm_patch_im2col(img, ws + L.patches, B, w->img_h, w->img_w_full, w->win_x0, w->win_w, w->patch, w->pad, dt, stream));
-  HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
   const float scale = 1.0f / sqrtf((float)(D / w->heads));
+  if (fold) HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_LN, w->pos, D, tokens, w->blocks[0].ln1_g));
+  else HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
   for (int i = 0; i < w->depth; ++i) {
     const hm_vit_block& b = w->blocks[i];
-    HM_TRY(hm_layernorm(x, b.ln1_g, b.ln1_b, h, dt, M, D, w->vit_eps, stream));
-    HM_TRY(gemm(h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
-    HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
-    HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, D, 0));
-    HM_TRY(hm_layernorm(x, b.ln2_g, b.ln2_b, h, dt, M, D, w->vit_eps, stream));
-    HM_TRY(gemm(h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0));
-    HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, D, 0));
+    if (fold) {
+      HM_TRY(gemm(h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_bias_ln, HM_EPI_LN_STORE, nullptr, 0, 0, b.qkv_colsum));
+      HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
+      HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_LN, x, D, 0, b.ln2_g));
+      HM_TRY(gemm(h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_bias_ln, HM_EPI_LN_GELU, nullptr, 0, 0, b.fc1_colsum));
+      if (i + 1 < w->depth) HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_LN, x, D, 0, w->blocks[i + 1].ln1_g));
+      else HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, D, 0));   // last_norm stays a kernel
+    } else {
+      HM_TRY(hm_layernorm(x, b.ln1_g, b.ln1_b, h, dt, M, D, w->vit_eps, stream));
+      HM_TRY(gemm(h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
+      HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
+      HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, D, 0));
+      HM_TRY(hm_layernorm(x, b.ln2_g, b.ln2_b, h, dt, M, D, w->vit_eps, stream));
+      HM_TRY(gemm(h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0));
+      HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, D, 0));
+    }
     if (i == 0 && after_first_block && hipEventRecord(after_first_block, (hipStream_t)stream) != hipSuccess)
       return hm_set_error(HM_ERR_HIP, "hm_hamer_forward_split: hipEventRecord failed");
   }

@@ -27,6 +27,9 @@ struct KArgs {                                    // kernel-side view of either 
   const void* X; const void* W; void* C; const float* bias; const float* resid;
   int M, N, K, ldx, ldw, ldc, ldr, resid_mod;
   int group_m;                                    // tile order: runs of group_m M-tiles per N-tile (L2 reuse of both panels)
+  // deferred LayerNorm (HM_EPI_RESID_LN produces, HM_EPI_LN_STORE / HM_EPI_LN_GELU consume)
+  const float* ln_gamma; void* ln_xg; float* ln_stats; const float* ln_colsum;
+  int ln_P;
   // convolution geometry (CONV only)
   const void* zeros;
   int H, Wd, Hout, Wout, ksz, stride, pad, cin_log2, taps;
@@ -84,13 +87,33 @@ constexpr int epi_stage_bytes(int MI, int NI) { return MI * 16 * epi_cgn(MI, NI)
 // (chunk ^= row & 15: conflict-free for the 16 rows of a piece), read back row-major, and every global
 // instruction then covers 4 full 256-byte row segments (128 B for 16-bit outputs).  Residual rows are fetched
 // row-major too, all issued before the LDS round trip so their latency overlaps it.
+//
+// Deferred LayerNorm.  LN(x) . W^T = rstd * (x*gamma . W^T - mean * colsum) + (b + W.beta), colsum[n] = sum_k W[n][k] gamma[k]:
+// the GEMM that produces the fp32 residual stream x (HM_EPI_RESID_LN) also stores x * gamma as the next GEMM's
+// 16-bit operand and, per 64-column group and row ([D/64][M][2]), the partial (sum, sum of squares) of x; the consuming GEMM
+// (HM_EPI_LN_STORE / HM_EPI_LN_GELU) reduces the partials to (mean, rstd) per tile row before its K loop
+// (`rowstat`, in LDS) and applies them here.  That removes the LayerNorm launch: 94 MB of HBM traffic per call
+// become 31 MB of extra stores in an epilogue that is already streaming the same rows.
+constexpr bool epi_ln_in(int EPI) { return EPI == HM_EPI_LN_STORE || EPI == HM_EPI_LN_GELU; }
+
+// sum over each aligned group of 8 lanes, on the VALU's DPP path (quad swaps, then the half-row mirror)
+__device__ __forceinline__ float row8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return v;
+}
+
 template <class T, int EPI, int MI, int NI>
-__device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI], int mb, int nb, int lane, char* wlds) {
+__device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI], int mb, int nb, int lane, char* wlds,
+                                         const float2* rowstat, const float* cbias, const float* cvec2) {
   using elem = typename T::elem;
   // n-subtiles per column group: <= 16 KB of LDS per wave; the residual epilogue splits that between the
   // transposed accumulators and the residual rows, which arrive by LDS-DMA (no registers, all in flight at once)
   constexpr int CGN0 = epi_cgn(MI, NI);
-  constexpr bool RES = EPI == HM_EPI_RESID_F32;
+  constexpr bool LNOUT = EPI == HM_EPI_RESID_LN, LNIN = epi_ln_in(EPI);
+  constexpr bool RES = EPI == HM_EPI_RESID_F32 || LNOUT;
+  constexpr bool ACT_GELU = EPI == HM_EPI_GELU || EPI == HM_EPI_LN_GELU;
   constexpr int CGN = (RES && CGN0 > 1) ? CGN0 / 2 : CGN0;
   constexpr int NCH = CGN * 4;                     // 16-byte chunks per staged row (4, 8 or 16)
   constexpr int RS = NCH * 16;                     // staged row stride in bytes
@@ -98,8 +121,14 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
   constexpr int ITS = MI * 16 / RPI;               // row-major instructions per column group
   const int arow = lane & 15, apiece = lane >> 4;  // accumulator layout
   const int rrow = lane / NCH, rslot = lane % NCH; // row-major layout
-  const float* __restrict__ bias = g.bias;
+  // cbias / cvec2: this wave's columns of the bias (zeros when there is none) and of ln_gamma / ln_colsum, staged in
+  // LDS by the kernel prologue -- a global load here sits on the epilogue's critical path once per column group
   char* rlds = wlds + MI * 16 * RS;                // residual rows (RES only)
+  // LNOUT: per-row partial (sum, sum of squares) of this lane's columns, one pair per row-major instruction
+  constexpr int CPG = LNOUT ? 64 / (CGN * 16) : 1;  // column groups per 64-column statistics group
+  static_assert(!LNOUT || ((CGN * 16 <= 64) && (64 % (CGN * 16) == 0) && (NI * 16) % 64 == 0), "LN statistics groups are 64 columns");
+  static_assert(!LNIN || NCH >= 8, "deferred-LN consumers use the 16-byte store path");
+  float s1[LNOUT ? ITS : 1], s2[LNOUT ? ITS : 1];
 #pragma unroll
   for (int cg = 0; cg < NI / CGN; ++cg) {
     const int ncol0 = nb + cg * CGN * 16;
@@ -125,23 +154,30 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
       }
     if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // LDS -> row-major, bias / activation / residual, coalesced stores
-    if constexpr ((EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU) && NCH >= 8) {
+    if constexpr ((EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU || LNIN) && NCH >= 8) {
       // 16-bit outputs: 8 columns (two staged chunks) per lane -> one 16-byte store, NCH/2 lanes per row
       constexpr int LPR = NCH / 2, RPI2 = 64 / LPR, ITS2 = MI * 16 / RPI2;
       const int row0 = lane / LPR, j = lane % LPR;
+      f32x4_t cs0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, cs1 = cs0;
+      const int nw = cg * CGN * 16 + 8 * j;         // column inside the wave's strip
+      if (LNIN) { cs0 = *(const f32x4_t*)(cvec2 + nw); cs1 = *(const f32x4_t*)(cvec2 + nw + 4); }
+      const f32x4_t bi0 = *(const f32x4_t*)(cbias + nw), bi1 = *(const f32x4_t*)(cbias + nw + 4);
 #pragma unroll 2
       for (int it = 0; it < ITS2; ++it) {
         const int row = it * RPI2 + row0, m = mb + row, n = ncol0 + 8 * j;
         const int sw = row & (NCH - 1);
         f32x4_t v0 = *(const f32x4_t*)(wlds + row * RS + ((2 * j) ^ sw) * 16);
         f32x4_t v1 = *(const f32x4_t*)(wlds + row * RS + ((2 * j + 1) ^ sw) * 16);
+        float2 st = float2{0.f, 1.f};
+        if (LNIN) st = rowstat[row];
         if (m >= g.M || n >= g.N) continue;
-        if (bias) { v0 += *(const f32x4_t*)(bias + n); v1 += *(const f32x4_t*)(bias + n + 4); }
+        if (LNIN) { v0 = (v0 - st.x * cs0) * st.y; v1 = (v1 - st.x * cs1) * st.y; }
+        v0 += bi0; v1 += bi1;
         typename T::vec8 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float a = v0[q], b = v1[q];
-          if (EPI == HM_EPI_GELU) { a = gelu_fast(a); b = gelu_fast(b); }
+          if (ACT_GELU) { a = gelu_fast(a); b = gelu_fast(b); }
           else if (EPI == HM_EPI_SILU) { a = silu(a); b = silu(b); }
           o[q] = (elem)a; o[4 + q] = (elem)b;
         }
@@ -160,6 +196,39 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
           *(typename T::vec4*)((elem*)g.C + (size_t)m * g.ldc + n) = h;
         }
       }
+    } else if constexpr (LNOUT) {
+      static_assert(RPI % NCH == 0 && NCH == 8, "the column of a lane must not depend on `it`; the row reduction is over 8 lanes");
+      if (cg % CPG == 0) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) s1[it] = s2[it] = 0.f;
+      }
+      const int n = ncol0 + ((rslot ^ (rrow & (NCH - 1))) << 2);     // same for every `it` (RPI % NCH == 0)
+      const bool ncol_ok = n < g.N;
+      const f32x4_t ga = *(const f32x4_t*)(cvec2 + (n - nb)), bi = *(const f32x4_t*)(cbias + (n - nb));
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int row = it * RPI + rrow, m = mb + row;
+        f32x4_t v = *(const f32x4_t*)(wlds + row * RS + rslot * 16);
+        const f32x4_t r = *(const f32x4_t*)(rlds + row * RS + rslot * 16);
+        if (m >= g.M || !ncol_ok) continue;
+        v += bi + r;
+        *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v;
+        s1[it] += (v[0] + v[1]) + (v[2] + v[3]);
+        s2[it] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        typename T::vec4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (elem)(v[q] * ga[q]);
+        *(typename T::vec4*)((elem*)g.ln_xg + (size_t)m * g.N + n) = o;
+      }
+      if (cg % CPG == CPG - 1) {                     // a 64-column group is complete: reduce over the 8 lanes of each row (DPP)
+        const int pidx = (nb + (cg / CPG) * 64) >> 6;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const float a = row8_sum(s1[it]), b = row8_sum(s2[it]);
+          const int m = mb + it * RPI + rrow;
+          if (rslot == 0 && m < g.M && pidx < g.ln_P) *(float2*)(g.ln_stats + ((size_t)pidx * g.M + m) * 2) = float2{a, b};
+        }
+      }
     } else {
 #pragma unroll 2
       for (int it = 0; it < ITS; ++it) {
@@ -169,7 +238,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         f32x4_t r = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (RES) r = *(const f32x4_t*)(rlds + row * RS + rslot * 16);
         if (m >= g.M || n >= g.N) continue;
-        if (bias) v += *(const f32x4_t*)(bias + n);
+        v += *(const f32x4_t*)(cbias + (n - nb));
         if (EPI == HM_EPI_GELU) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
@@ -318,6 +387,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) stage(s, s);
+  // deferred-LN consumer: (mean, rstd) of this tile's rows from the producer's 64-column partials, kept in LDS past
+  // the ring; the K loop's barriers order these writes before the epilogue reads
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES, EPI_BYTES = NW * epi_stage_bytes(MI, NI);
+  float2* rowstat = (float2*)(smem + (RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES));
+  float* colvec = (float*)(rowstat + BM);              // [2][BN]: bias (or zeros) | ln_gamma or ln_colsum
+  for (int c = tid; c < BN; c += 64 * NW) {
+    const int n = min(n0 + c, g.N - 1);
+    colvec[c] = g.bias ? g.bias[n] : 0.f;
+    if constexpr (EPI == HM_EPI_RESID_LN) colvec[BN + c] = g.ln_gamma[n];
+    if constexpr (epi_ln_in(EPI)) colvec[BN + c] = g.ln_colsum[n];
+  }
+  if constexpr (epi_ln_in(EPI)) {
+    for (int r = tid; r < BM; r += 64 * NW) rowstat[r] = ((const float2*)g.ln_stats)[min(m0 + r, g.M - 1)];   // (mean, rstd) per row
+  }
   int rd = 0, wrb = STAGES - 1;                        // ring slots: read tile kt, write tile kt+STAGES-1
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed: in steady state the STAGES-2 newer tiles may still be in flight
@@ -349,144 +432,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
       for (int b = 0; b < MI; ++b) asm volatile("" :: "v"(acc[a][b]));
     return;
   }
-  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI));
+  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI),
+                           rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI);
 }
 
-// Software-pipelined variant for the big plain GEMMs: 256x256 tile, K slabs of 32 in a 4-deep LDS ring
-// (3 slabs of LDS-DMA in flight), and the MFMA fragments DOUBLE-BUFFERED in registers: while the MFMAs of
-// slab t run, the ds_reads of slab t+1 and the LDS-DMA of slab t+3 are already issued, so after the one
-// barrier per slab every wave has matrix work ready (the plain kernel above reads its fragments right after
-// the barrier, when both waves of a SIMD stall on LDS together).
-template <class T, int EPI, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_pipe_kernel(const KArgs g) {
-  constexpr int BK = 32, STAGES = 4;
-  constexpr int NW = WM * WN;
-  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
-  constexpr int ROWB = 64, CH = 4, RPI = 16;
-  constexpr int XI = BM / NW / RPI, WI = BN / NW / RPI;
-  static_assert(BM % (NW * RPI) == 0 && BN % (NW * RPI) == 0, "tile rows must split into whole DMA pieces per wave");
-  constexpr int XTILE_BYTES = BM * BK * 2, WTILE_BYTES = BN * BK * 2;
-  constexpr int STAGE_BYTES = XTILE_BYTES + WTILE_BYTES;
-  constexpr int LOADS = XI + WI;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  using vec8 = typename T::vec8;
-  using elem = typename T::elem;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int wr = wave / WN, wc = wave % WN;
-  const elem* __restrict__ X = (const elem*)g.X;
-  const elem* __restrict__ W = (const elem*)g.W;
-
-  const int srow = lane / CH;
-  const int chunk = (lane % CH) ^ ((srow >> 2) & 3);
-  const elem* xsrc[XI];
-  const elem* wsrc[WI];
-#pragma unroll
-  for (int i = 0; i < XI; ++i) {
-    int gm = m0 + wave * XI * RPI + i * RPI + srow;
-    gm = gm < g.M ? gm : g.M - 1;
-    xsrc[i] = X + (size_t)gm * g.ldx + chunk * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < WI; ++i) {
-    int gn = n0 + wave * WI * RPI + i * RPI + srow;
-    gn = gn < g.N ? gn : g.N - 1;
-    wsrc[i] = W + (size_t)gn * g.ldw + chunk * 8;
-  }
-  auto stage = [&](int t) {
-    char* lx = smem + (t & (STAGES - 1)) * STAGE_BYTES + wave * XI * 1024;
-    char* lw = smem + (t & (STAGES - 1)) * STAGE_BYTES + XTILE_BYTES + wave * WI * 1024;
-#pragma unroll
-    for (int i = 0; i < XI; ++i) glds16(xsrc[i] + (size_t)t * BK, lx + i * 1024);
-#pragma unroll
-    for (int i = 0; i < WI; ++i) glds16(wsrc[i] + (size_t)t * BK, lw + i * 1024);
-  };
-
-  f32x4_t acc[NI][MI];
-#pragma unroll
-  for (int a = 0; a < NI; ++a)
-#pragma unroll
-    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15, fch = lane >> 4;
-  const int coff = (fch ^ ((lane >> 2) & 3)) * 16;
-  const int woff = (wc * 16 * NI + frow) * ROWB + coff, xoff = (wr * 16 * MI + frow) * ROWB + coff;
-  auto read_frags = [&](int t, vec8 (&wf)[NI], vec8 (&xf)[MI]) {
-    const char* lx = smem + (t & (STAGES - 1)) * STAGE_BYTES;
-    const char* lw = lx + XTILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + woff + i * 16 * ROWB);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + xoff + i * 16 * ROWB);
-  };
-  auto mfmas = [&](vec8 (&wf)[NI], vec8 (&xf)[MI]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // one slab: make slab t+1 visible, prefetch its fragments and the LDS-DMA of slab t+3, run the MFMAs of slab t
-  auto step = [&](int t, int nk, vec8 (&wc_)[NI], vec8 (&xc_)[MI], vec8 (&wn_)[NI], vec8 (&xn_)[MI]) {
-    if (t + 1 < nk) {
-      if (t + 2 < nk) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();      // slab t+1 landed (slab t+2 may be in flight)
-      __builtin_amdgcn_s_barrier();
-      read_frags(t + 1, wn_, xn_);
-      if (t + 3 < nk) stage(t + 3);                                    // overwrites slab t-1: consumed before this barrier
-    }
-    mfmas(wc_, xc_);
-    // the fragment reads issued above had the whole MFMA phase to land: retire them here (free), with the
-    // compiler-visible builtin, so that across the loop back-edge hipcc does not put an lgkmcnt(0) between
-    // the next slab's ds_reads and its MFMAs (0xC07F = lgkmcnt(0) only)
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-  };
-
-  const int nk = g.K / BK;                                             // host guarantees nk >= 4
-  stage(0); stage(1); stage(2);
-  wait_vmcnt<2 * LOADS>();
-  __builtin_amdgcn_s_barrier();
-  vec8 wa[NI], xa[MI], wb[NI], xb[MI];
-  read_frags(0, wa, xa);
-  __builtin_amdgcn_s_waitcnt(0xC07F);                                 // nothing pending on any edge into the loop
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    step(t, nk, wa, xa, wb, xb);
-    step(t + 1, nk, wb, xb, wa, xa);
-  }
-  if (t < nk) step(t, nk, wa, xa, wb, xb);
-  __builtin_amdgcn_s_barrier();
-  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI));
-}
-
-template <class T, int EPI, int WM, int WN, int MI, int NI>
-int launch_pipe(const KArgs& g, hipStream_t s) {
-  constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
-  constexpr int RING = 4 * (BM + BN) * 32 * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI);
-  constexpr int LDS = RING > EPIB ? RING : EPIB;
-  auto kern = gemm_pipe_kernel<T, EPI, WM, WN, MI, NI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "gemm: cannot raise the dynamic LDS limit");
-    attr_set = true;
-  }
-  if (g.K < 128) return hm_set_error(HM_ERR_ARG, "hm_gemm: the pipelined tile needs K >= 128");
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, s, g);
-  return hm_check_launch("hm_gemm");
+// partial (sum, sum of squares) per 64 columns [P][M][2] -> (mean, rstd) per row [M][2]
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ fin, int M, int P,
+                                                          float invD, float eps) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float a = 0.f, b = 0.f;
+#pragma unroll 8
+  for (int p = 0; p < P; ++p) { const float2 v = part[(size_t)p * M + m]; a += v.x; b += v.y; }
+  const float mean = a * invD;
+  fin[m] = float2{mean, 1.0f / sqrtf(fmaxf(b * invD - mean * mean, 0.f) + eps)};
 }
 
 template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
 int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
   constexpr int RING = STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI);
-  constexpr int LDS = RING > EPIB ? RING : EPIB;
+  constexpr int LDS = (RING > EPIB ? RING : EPIB) + BM * 8 + BN * 8;     // + row statistics + column vectors
   auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -523,8 +489,6 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 13: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 91>(g, s, "hm_gemm"); // ABLATION (wrong results): no MFMA
     case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // ABLATION: LDS-DMA + waits + barriers only
     case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ABLATION: ds_read + MFMA + barriers, no loads
-    case 18: return launch_pipe<T, EPI, 4, 2, 4, 8>(g, s);                             // 256x256x32 ring of 4, fragments double-buffered
-    case 19: return launch_pipe<T, EPI, 2, 4, 8, 4>(g, s);                             // same, waves 2x4 (128x64 each)
     case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // ABLATION: no epilogue
     case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
@@ -532,6 +496,17 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 16: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 94>(g, s, "hm_gemm"); // EXPERIMENT: fill only, tile-major operands
     case 17: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 95>(g, s, "hm_gemm"); // EXPERIMENT: full kernel, tile-major operands
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
+  }
+}
+
+// The deferred-LayerNorm epilogues exist for the production tiles only (0, 8, 9, 10).
+template <class T, int EPI>
+int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
+  switch (variant) {
+    case 0: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false>(g, s, "hm_gemm");
+    case 8: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false>(g, s, "hm_gemm");
+    case 9: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 1>(g, s, "hm_gemm");
+    default: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
   }
 }
 
@@ -558,6 +533,9 @@ int launch_gemm_epi(const KArgs& g, int epilogue, hipStream_t s) {
     case HM_EPI_RESID_F32: return launch_gemm<T, HM_EPI_RESID_F32>(g, v, s);
     case HM_EPI_F32: return launch_gemm<T, HM_EPI_F32>(g, v, s);
     case HM_EPI_SILU: return launch_gemm<T, HM_EPI_SILU>(g, v, s);
+    case HM_EPI_RESID_LN: return launch_gemm_ln<T, HM_EPI_RESID_LN>(g, v, s);
+    case HM_EPI_LN_STORE: return launch_gemm_ln<T, HM_EPI_LN_STORE>(g, v, s);
+    case HM_EPI_LN_GELU: return launch_gemm_ln<T, HM_EPI_LN_GELU>(g, v, s);
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown epilogue");
   }
 }
@@ -581,6 +559,13 @@ int launch_conv(const KArgs& g, int epilogue, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int hm_ln_finalize(const float* partials, float* row_stats, int M, int D, float eps, void* stream_) {
+  if (!partials || !row_stats || M <= 0 || D <= 0 || D % 64 != 0) return hm_set_error(HM_ERR_ARG, "hm_ln_finalize: bad arguments");
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream_, (const float2*)partials,
+                     (float2*)row_stats, M, D / 64, 1.0f / (float)D, eps);
+  return hm_check_launch("hm_ln_finalize");
+}
+
 extern "C" int hm_gemm_set_group_m(int gm) {
   if (gm < 1 || gm > 64) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_group_m: 1..64");
   g_group_m = gm;
@@ -603,14 +588,25 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
   if (g.ldx % 8 != 0 || g.ldw % 8 != 0) return hm_set_error(HM_ERR_ARG, "hm_gemm: ldx/ldw must be multiples of 8 elements");
   if (g.ldx < g.K || g.ldw < g.K || g.ldc < g.N) return hm_set_error(HM_ERR_ARG, "hm_gemm: leading dimension too small");
   if (!g.X || !g.W || !g.C) return hm_set_error(HM_ERR_ARG, "hm_gemm: null operand");
-  if (g.epilogue == HM_EPI_RESID_F32 && (!g.resid || g.ldr < g.N || g.ldr % 4 != 0))
+  const bool ln_out = g.epilogue == HM_EPI_RESID_LN, ln_in = g.epilogue == HM_EPI_LN_STORE || g.epilogue == HM_EPI_LN_GELU;
+  if ((g.epilogue == HM_EPI_RESID_F32 || ln_out) && (!g.resid || g.ldr < g.N || g.ldr % 4 != 0))
     return hm_set_error(HM_ERR_ARG, "hm_gemm: residual epilogue needs resid and ldr >= N, ldr % 4 == 0");
+  if (ln_out && (!g.ln_gamma || !g.ln_xg || !g.ln_stats || g.N % 64 != 0))
+    return hm_set_error(HM_ERR_ARG, "hm_gemm: HM_EPI_RESID_LN needs ln_gamma, ln_xg, ln_stats and N % 64 == 0");
+  if (ln_in && (!g.ln_stats || !g.ln_colsum || g.N % 8 != 0 || g.ldc % 8 != 0))
+    return hm_set_error(HM_ERR_ARG, "hm_gemm: HM_EPI_LN_* need ln_stats, ln_colsum, N % 8 == 0, ldc % 8 == 0");
+  if ((ln_out || ln_in) && (((uintptr_t)g.ln_gamma | (uintptr_t)g.ln_xg | (uintptr_t)g.ln_stats | (uintptr_t)g.ln_colsum) & 15))
+    return hm_set_error(HM_ERR_ARG, "hm_gemm: deferred-LN pointers must be 16-byte aligned");
   if (((uintptr_t)g.X | (uintptr_t)g.W | (uintptr_t)g.C | (uintptr_t)g.bias | (uintptr_t)g.resid) & 15)
     return hm_set_error(HM_ERR_ARG, "hm_gemm: pointers must be 16-byte aligned");
   KArgs k{};
   k.X = g.X; k.W = g.W; k.C = g.C; k.bias = g.bias; k.resid = g.resid;
   k.M = g.M; k.N = g.N; k.K = g.K; k.ldx = g.ldx; k.ldw = g.ldw; k.ldc = g.ldc; k.ldr = g.ldr; k.resid_mod = g.resid_mod;
   k.group_m = g_group_m;
+  if (ln_out) { k.ln_gamma = g.ln_gamma; k.ln_xg = g.ln_xg; k.ln_stats = g.ln_stats; k.ln_P = g.N / 64; }
+  if (ln_in) {
+    k.ln_stats = g.ln_stats; k.ln_colsum = g.ln_colsum;
+  }
   HmProfScope prof(HM_K_GEMM, g.epilogue, g.M, g.N, g.K, stream);
   if (g.dtype == HM_DTYPE_BF16) return launch_gemm_epi<TBf16>(k, g.epilogue, stream);
   if (g.dtype == HM_DTYPE_F16) return launch_gemm_epi<TF16>(k, g.epilogue, stream);

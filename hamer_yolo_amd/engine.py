@@ -22,7 +22,7 @@ from .synth import HamerConfig
 
 class HamerEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], mano: Dict[str, torch.Tensor],
-                 cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.bfloat16):
+                 cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.bfloat16, fold_ln: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise L.HipLibraryError("HamerEngine needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = L.load()
@@ -47,6 +47,17 @@ class HamerEngine:
             self._keep.append(t)
             return t
 
+        # deferred LayerNorm (hm_gemm HM_EPI_RESID_LN / HM_EPI_LN_*): LN1/LN2 of every block are folded into the
+        # neighbouring GEMMs; needs colsum = W16 . gamma and bias + W16 . beta of the 16-bit weights actually used
+        if fold_ln is None:
+            fold_ln = os.environ.get("HAMER_FOLD_LN", "0") == "1"    # measured equal to the LayerNorm kernel at B=64: off
+        self.fold_ln = bool(fold_ln) and v.embed_dim % 64 == 0
+
+        def ln_fold(W, bias, gamma, beta):
+            Wd = W.detach().to(self.device, torch.float32).to(dtype).to(torch.float64)
+            g64, b64 = gamma.detach().to(self.device, torch.float64), beta.detach().to(self.device, torch.float64)
+            return f32(Wd @ g64), f32(bias.detach().to(self.device, torch.float64) + Wd @ b64)
+
         D = v.embed_dim
         self.blocks = (L.VitBlock * v.depth)()
         for i in range(v.depth):
@@ -58,6 +69,11 @@ class HamerEngine:
             b.proj_w, b.proj_b = L.ptr(w16(sd[p + "attn.proj.weight"])), L.ptr(f32(sd[p + "attn.proj.bias"]))
             b.fc1_w, b.fc1_b = L.ptr(w16(sd[p + "mlp.fc1.weight"])), L.ptr(f32(sd[p + "mlp.fc1.bias"]))
             b.fc2_w, b.fc2_b = L.ptr(w16(sd[p + "mlp.fc2.weight"])), L.ptr(f32(sd[p + "mlp.fc2.bias"]))
+            if self.fold_ln:
+                cs, bl = ln_fold(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+                b.qkv_colsum, b.qkv_bias_ln = L.ptr(cs), L.ptr(bl)
+                cs, bl = ln_fold(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+                b.fc1_colsum, b.fc1_bias_ln = L.ptr(cs), L.ptr(bl)
         pos = sd["backbone.pos_embed"].to(torch.float32)
         pos = pos[0, 1:] + pos[0, :1]
 

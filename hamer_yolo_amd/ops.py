@@ -28,19 +28,38 @@ def _dev(*ts):
 
 
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = L.HM_EPI_STORE,
-         resid: Optional[torch.Tensor] = None, resid_mod: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = epilogue(x @ w.T + bias); x (M,K), w (N,K) 16-bit row-major."""
-    _dev(x, w, bias, resid, out)
+         resid: Optional[torch.Tensor] = None, resid_mod: int = 0, out: Optional[torch.Tensor] = None,
+         ln_gamma: Optional[torch.Tensor] = None, ln_xg: Optional[torch.Tensor] = None,
+         ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epilogue(x @ w.T + bias); x (M,K), w (N,K) 16-bit row-major.  Deferred LayerNorm: HM_EPI_RESID_LN also
+    fills ln_xg (M,N) 16-bit = out * ln_gamma and ln_stats (N/64, M, 2); HM_EPI_LN_STORE / HM_EPI_LN_GELU read
+    ln_stats (M, 2) = ln_finalize(partials) and ln_colsum (N,)."""
+    _dev(x, w, bias, resid, out, ln_gamma, ln_xg, ln_stats, ln_colsum)
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1 and x.dtype == w.dtype
-    f32_out = epilogue in (L.HM_EPI_RESID_F32, L.HM_EPI_F32)
+    f32_out = epilogue in (L.HM_EPI_RESID_F32, L.HM_EPI_F32, L.HM_EPI_RESID_LN)
+    if epilogue == L.HM_EPI_RESID_LN:
+        assert ln_xg.shape == (M, N) and ln_xg.is_contiguous() and ln_xg.dtype == x.dtype
+        assert ln_stats.shape == (N // 64, M, 2) and ln_stats.is_contiguous() and ln_gamma.shape == (N,)
+    if epilogue in (L.HM_EPI_LN_STORE, L.HM_EPI_LN_GELU):
+        assert ln_stats.shape == (M, 2) and ln_stats.is_contiguous() and ln_colsum.shape == (N,)
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32 if f32_out else x.dtype)
     assert out.shape == (M, N) and out.stride(1) == 1
     a = L.GemmArgs(L.ptr(x), L.ptr(w), L.ptr(out), L.ptr(bias), L.ptr(resid), M, N, K, x.stride(0), w.stride(0),
-                   out.stride(0), resid.stride(0) if resid is not None else 0, resid_mod, epilogue, _dt(x))
+                   out.stride(0), resid.stride(0) if resid is not None else 0, resid_mod, epilogue, _dt(x),
+                   L.ptr(ln_gamma), L.ptr(ln_xg), L.ptr(ln_stats), L.ptr(ln_colsum))
     L.check(L.load().hm_gemm(C.byref(a), L.current_stream()), "hm_gemm")
+    return out
+
+
+def ln_finalize(partials: torch.Tensor, eps: float) -> torch.Tensor:
+    """(D/64, M, 2) partial (sum, sum of squares) -> (M, 2) (mean, rstd)."""
+    _dev(partials)
+    P, M, _ = partials.shape
+    out = torch.empty(M, 2, device=partials.device, dtype=torch.float32)
+    L.check(L.load().hm_ln_finalize(L.ptr(partials), L.ptr(out), M, P * 64, eps, L.current_stream()), "hm_ln_finalize")
     return out
 
 

@@ -34,7 +34,13 @@ enum {
   HM_EPI_GELU = 1,      /* C(16-bit) = gelu_erf(acc + bias)        vit.py:82-87    */
   HM_EPI_RESID_F32 = 2, /* C(f32)    = acc + bias + resid[m % resid_mod][n]        */
   HM_EPI_F32 = 3,       /* C(f32)    = acc + bias                                  */
-  HM_EPI_SILU = 4       /* C(16-bit) = silu(acc + bias)      yolov7 common.py:114  */
+  HM_EPI_SILU = 4,      /* C(16-bit) = silu(acc + bias)      yolov7 common.py:114  */
+  /* deferred LayerNorm (Block.forward vit.py:148-151: x += f(LN(x))): the GEMM that writes the residual
+   * stream also emits the next LayerNorm's statistics and x*gamma, the GEMM that follows applies them:
+   * LN(x).W^T + b = rstd * ((x*gamma).W^T - mean * colsum) + (b + W.beta), colsum[n] = sum_k W[n][k]*gamma[k] */
+  HM_EPI_RESID_LN = 5,  /* RESID_F32, plus ln_xg = C*ln_gamma (16-bit) and ln_stats     */
+  HM_EPI_LN_STORE = 6,  /* C(16-bit) = rstd*(acc - mean*ln_colsum) + bias               */
+  HM_EPI_LN_GELU = 7    /* C(16-bit) = gelu_erf(rstd*(acc - mean*ln_colsum) + bias)     */
 };
 
 typedef struct hm_gemm_args {
@@ -48,12 +54,20 @@ typedef struct hm_gemm_args {
   int resid_mod;      /* >0: residual row = m % resid_mod (positional embedding)      */
   int epilogue;
   int dtype;
+  /* deferred LayerNorm, NULL / 0 for the other epilogues */
+  const float* ln_gamma;  /* RESID_LN: [N] gamma of the LayerNorm that reads C                            */
+  void* ln_xg;            /* RESID_LN: out [M][N] 16-bit, C * gamma (the consuming GEMM's X)              */
+  float* ln_stats;        /* RESID_LN: out [N/64][M][2] = (sum, sum of squares) of C per 64 columns;
+                             LN_*: in [M][2] = (mean, rstd) per row, made from those by hm_ln_finalize     */
+  const float* ln_colsum; /* LN_*: [N] sum_k W[n][k] * gamma[k] over the 16-bit W; bias = b + W.beta      */
 } hm_gemm_args;
 
 /* nn.Linear forward on MFMA: C = epilogue(X . W^T).  Replaces the aten::addmm calls behind
  * Attention.qkv/.proj (vit.py:114,:124), Mlp.fc1/.fc2 (vit.py:83,:85), PatchEmbed.proj
  * (vit.py:172, after hm_patch_im2col) and CrossAttention.to_kv (pose_transformer.py:114). */
 int hm_gemm(const hm_gemm_args* args, void* stream);
+/* HM_EPI_RESID_LN partials [D/64][M][2] -> row_stats [M][2] = (mean, 1/sqrt(var + eps)) for HM_EPI_LN_*. */
+int hm_ln_finalize(const float* partials, float* row_stats, int M, int D, float eps, void* stream);
 /* Tuning hook: pin the GEMM tile configuration (0..5, see gemm.hip); -1 restores the default
  * (also settable through the HM_GEMM_VARIANT environment variable).  Results do not depend on it
  * beyond fp32 summation order. */
@@ -136,6 +150,10 @@ typedef struct hm_vit_block {
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const void *qkv_w, *proj_w, *fc1_w, *fc2_w;       /* 16-bit [N][K]                 */
   const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+  /* optional (all four, in every block, or none): deferred-LayerNorm operands, see HM_EPI_RESID_LN.
+   * *_colsum[n] = sum_k W[n][k]*ln_g[k] over the 16-bit weights, *_bias_ln = b + W.ln_b.  When present
+   * hm_hamer_forward runs no LayerNorm kernel inside the blocks. */
+  const float *qkv_colsum, *qkv_bias_ln, *fc1_colsum, *fc1_bias_ln;
 } hm_vit_block;
 
 typedef struct hm_dec_layer {

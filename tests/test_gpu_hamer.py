@@ -20,17 +20,20 @@ from oracle import hamer_ref as R
 TOL = 1e-3   # BASELINE.json north_star: "within 1e-3 abs"
 
 
-def _engine(cfg, seed, dtype=torch.bfloat16, mano_seed=0):
+def _engine(cfg, seed, dtype=torch.bfloat16, mano_seed=0, fold_ln=None):
     sd = synth.hamer_state_dict(cfg, seed=seed, bf16_representable=True)
     mp = synth.mano_params(seed=mano_seed)
-    return HamerEngine(sd, mp, cfg, dtype=dtype), sd, mp
+    return HamerEngine(sd, mp, cfg, dtype=dtype, fold_ln=fold_ln), sd, mp
 
 
+# fold_ln: LayerNorm deferred into the neighbouring GEMMs, or run as its own kernel (the default)
+@pytest.mark.parametrize("fold_ln", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_tiny_forward_vs_reference_golden(golden_dir, dtype):
+def test_tiny_forward_vs_reference_golden(golden_dir, dtype, fold_ln):
     g = np.load(os.path.join(golden_dir, "hamer_tiny.npz"))
     cfg = synth.tiny_config()
-    eng, sd, mp = _engine(cfg, int(g["seed"]), dtype)
+    eng, sd, mp = _engine(cfg, int(g["seed"]), dtype, fold_ln=fold_ln)
+    assert eng.fold_ln == fold_ln
     img = synth.normalize_crops(synth.crops_u8(3, seed0=int(g["crop_seed0"])))
     out = eng.forward(img.cuda(), want_tokens=True)
     torch.cuda.synchronize()
@@ -42,7 +45,8 @@ def test_tiny_forward_vs_reference_golden(golden_dir, dtype):
     np.testing.assert_allclose(out["rotmats"].cpu().numpy(), g["rotmats"], atol=TOL, rtol=0)
     # bf16-emulating oracle: same rounding points, so the gap is accumulation order only
     with torch.no_grad():
-        emu = R.hamer_forward(sd, mp, img, cfg, emu=True) if dtype == torch.bfloat16 else None
+        # (the explicit-LN path only: deferred LN rounds x*gamma instead of LN(x))
+        emu = R.hamer_forward(sd, mp, img, cfg, emu=True) if dtype == torch.bfloat16 and not fold_ln else None
         ref = R.hamer_forward(sd, mp, img, cfg, emu=False)
     for k_out, k_ref in (("pred_vertices", "pred_vertices"), ("pred_keypoints_3d", "pred_keypoints_3d"),
                          ("pred_keypoints_2d", "pred_keypoints_2d")):
@@ -53,14 +57,15 @@ def test_tiny_forward_vs_reference_golden(golden_dir, dtype):
         np.testing.assert_allclose(out["pred_vertices"].cpu().numpy(), emu["pred_vertices"].numpy(), atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("fold_ln", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_vith_forward_vs_reference_golden(golden_dir, dtype):
+def test_vith_forward_vs_reference_golden(golden_dir, dtype, fold_ln):
     """Full ViT-H/16 + 6-layer decoder; expected values from the reference vit.py / pose_transformer.py."""
     g = np.load(os.path.join(golden_dir, "hamer_vith.npz"))
     cfg = synth.HamerConfig()
     sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]), device="cuda", bf16_representable=True)
     mp = synth.mano_params(seed=0)
-    eng = HamerEngine(sd, mp, cfg, dtype=dtype)
+    eng = HamerEngine(sd, mp, cfg, dtype=dtype, fold_ln=fold_ln)
     img = synth.normalize_crops(synth.crops_u8(2, seed0=int(g["crop_seed0"])))
     out = eng.forward(img.cuda(), want_tokens=True)
     torch.cuda.synchronize()
