@@ -1,8 +1,12 @@
 // Attention.forward core of the ViT backbone (vit.py:115-123): softmax(scale * q k^T) v for
-// 192 tokens, 16 heads of head_dim 80.  One workgroup (4 waves) per (crop, head); K and V of the
-// head are staged once in LDS (63 KB, plain 16-byte copies), each wave owns 48 queries (3 MFMA
-// tiles).  V is consumed TRANSPOSED (the A operand of O^T = V^T . P^T) straight from its row-major
-// image with ds_read_b64_tr_b16, the gfx950 transposing LDS read.
+// 192 tokens, 16 heads of head_dim 80.  HBM-bound (94 MB of QKV in, 31 MB out per layer at B = 64,
+// 12 GFLOP), so the kernel is organised around the copy, not the math: PERSISTENT workgroups (one per
+// CU) walk the (crop, head) items; K and V of item i+1 stream into the second half of a 126 KB LDS
+// double buffer by LDS-DMA (and its Q rows into registers) while the 12 wavefronts compute item i,
+// one 16-query MFMA tile each.  (One workgroup per item with the copy in front ran every CU's copy
+// at the same moment and left HBM idle during the math: 38-43 us per layer against 19 us for the
+// copy alone; this form: 31.5 us, of which 28 us are the copies and stores by themselves.)  V is consumed TRANSPOSED (the A operand of O^T = V^T . P^T) straight from its
+// row-major image with ds_read_b64_tr_b16, the gfx950 transposing LDS read.
 //
 // Layout trick (no cross-lane traffic for P): scores are computed TRANSPOSED,
 // S^T = K . Q^T with mfma_16x16x32 (A = K rows, B = Q^T), so lane l holds, for query l&15,
@@ -25,7 +29,10 @@ constexpr int KSTR = 88;      // K row stride in LDS (elements): 176 B rows, con
 constexpr int VSTR = 80;      // V row stride in LDS (elements): 160 B = 40 dwords, 8 rows x 32 B tile the 64 banks
 constexpr int KS_BYTES = T * KSTR * 2;
 constexpr int VT_BYTES = T * VSTR * 2;
-constexpr int ATT_LDS = KS_BYTES + VT_BYTES;   // 64,512 B -> 2 workgroups per CU
+constexpr int BUF_BYTES = KS_BYTES + VT_BYTES;  // 64,512 B per (crop, head)
+constexpr int NWAVE = T / 16;                   // 12 wavefronts, one 16-query tile each
+constexpr int OTILE_BYTES = 16 * HD * 2;        // a wave's output tile, staged so rows leave as 160-byte runs
+constexpr int ATT_LDS = 2 * BUF_BYTES + NWAVE * OTILE_BYTES;   // double buffer 129,024 B + 30,720 B: one workgroup per CU
 
 // ds_read_b64_tr_b16: within each 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
 // 4 x 16 block; lane i receives column i of the 4 rows.  EXEC must be all ones.
@@ -35,55 +42,95 @@ template <class V4> __device__ __forceinline__ V4 lds_read_tr4(const void* p) {
   return __builtin_bit_cast(V4, v);
 }
 
+// LDS-DMA hidden from hipcc (inline asm; M0 = destination base, written and restored in the same statement).  Issued
+// through the builtin, hipcc knows an LDS write is pending and puts vmcnt(0) in front of the next LDS read that might
+// alias it -- here the V reads of the item being computed, i.e. it would wait for the NEXT item's copy in the middle
+// of the math.  The copy's completion is counted by hand instead: wait_vm0() + barrier at the top of every step.
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+// s_waitcnt vmcnt(0) through the builtin (simm16: expcnt and lgkmcnt fields at their maxima): hipcc's waitcnt pass
+// sees it.  After an inline-asm wait it still believes the Q loads of the previous step are pending and puts its own
+// vmcnt(0) in front of their first use -- behind the next item's copies, which serialises copy and math.
+__device__ __forceinline__ void wait_vm0() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
+}
+
 template <class TT>
-__global__ __launch_bounds__(256, 2) void vit_attention_kernel(const typename TT::elem* __restrict__ qkv,
-                                                               typename TT::elem* __restrict__ out, int heads,
-                                                               float scale_log2e) {
+__global__ __launch_bounds__(64 * NWAVE, 3) void vit_attention_kernel(const typename TT::elem* __restrict__ qkv,
+                                                                    typename TT::elem* __restrict__ out, int heads,
+                                                                    int items, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using elem = typename TT::elem;
   using vec8 = typename TT::vec8;
   using vec4 = typename TT::vec4;
-  elem* Ks = (elem*)smem;
-  elem* Vs = (elem*)(smem + KS_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int C = heads * HD;            // embed dim
   const size_t ld = (size_t)3 * C;
-  const elem* base = qkv + (size_t)b * T * ld + (size_t)h * HD;
-
-  // ---- stage K and V (both row-major) for this head
-  for (int c = tid; c < T * (HD / 8); c += 256) {
-    const int t = c / (HD / 8), ch = c % (HD / 8);
-    *(vec8*)(Ks + t * KSTR + ch * 8) = *(const vec8*)(base + (size_t)t * ld + C + ch * 8);
-    *(vec8*)(Vs + t * VSTR + ch * 8) = *(const vec8*)(base + (size_t)t * ld + 2 * C + ch * 8);
-  }
-  __syncthreads();
-
   const int g = lane >> 4, li = lane & 15;
   vec8 zero8;
 #pragma unroll
   for (int i = 0; i < 8; ++i) zero8[i] = (elem)0.0f;
 
-  for (int qt = 0; qt < 3; ++qt) {
-    const int q = wave * 48 + qt * 16 + li;   // this lane's query row
-    const elem* qrow = base + (size_t)q * ld;
-    vec8 qf[3];
+  // Copy of one item: K and V (both row-major) by LDS-DMA -- the LDS image is lane-linear (16 B per lane, 1 KiB per
+  // instruction), so chunk c of the image maps to (row c / CPR, 16-byte column c % CPR); K rows carry one pad chunk
+  // (CPR = 11: it re-reads column 0, never used), V rows none (CPR = 10) -- and this wave's 16 query rows to registers.
+  auto issue = [&](int item, int buf, vec8 (&qf)[3]) {
+    const elem* base = qkv + (size_t)(item / heads) * T * ld + (size_t)(item % heads) * HD;
+    char* Kb = smem + buf * BUF_BYTES;
+    char* Vb = Kb + KS_BYTES;
+    constexpr int KCH = T * (KSTR / 8), VCH = T * (VSTR / 8);       // 2112 and 1920 chunks
+    for (int c0 = wave * 64; c0 < KCH; c0 += 64 * NWAVE) {
+      const int c = c0 + lane, t = c / (KSTR / 8), ch = c % (KSTR / 8);
+      glds16_hidden(base + (size_t)t * ld + C + (ch < HD / 8 ? ch : 0) * 8, Kb + c0 * 16);
+    }
+    for (int c0 = wave * 64; c0 < VCH; c0 += 64 * NWAVE) {
+      const int c = c0 + lane, t = c / (VSTR / 8), ch = c % (VSTR / 8);
+      glds16_hidden(base + (size_t)t * ld + 2 * C + ch * 8, Vb + c0 * 16);
+    }
+    const elem* qrow = base + (size_t)(wave * 16 + li) * ld;
     qf[0] = *(const vec8*)(qrow + 8 * g);
     qf[1] = *(const vec8*)(qrow + 32 + 8 * g);
     qf[2] = g < 2 ? *(const vec8*)(qrow + 64 + 8 * g) : zero8;
+  };
 
-    // S^T tiles: st[kt][r] = score(key kt*16 + 4g + r, query li)
+  auto compute = [&](int item, int buf, const vec8 (&qf)[3]) {
+    const elem* Ks = (const elem*)(smem + buf * BUF_BYTES);
+    const elem* Vs = (const elem*)(smem + buf * BUF_BYTES + KS_BYTES);
+    const int b = item / heads, h = item % heads;
+    const int q = wave * 16 + li;             // this lane's query row
+    // S^T tiles: st[kt][r] = score(key kt*16 + 4g + r, query li).  K fragments are fetched two key tiles ahead of
+    // the MFMAs that use them (left to itself hipcc waits lgkmcnt(0) in front of every MFMA: ~200 cycles each)
     f32x4_t st[12];
+    vec8 kf[2][2][3];
+    auto load_k = [&](int kb, int pair) {
 #pragma unroll
-    for (int kt = 0; kt < 12; ++kt) {
-      const elem* krow = Ks + (kt * 16 + li) * KSTR + 8 * g;
-      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      acc = TT::mfma(*(const vec8*)(krow), qf[0], acc);
-      acc = TT::mfma(*(const vec8*)(krow + 32), qf[1], acc);
-      const vec8 k2 = g < 2 ? *(const vec8*)(krow + 64) : zero8;
-      acc = TT::mfma(k2, qf[2], acc);
-      st[kt] = acc;
+      for (int j = 0; j < 2; ++j) {
+        const elem* krow = Ks + ((pair * 2 + j) * 16 + li) * KSTR + 8 * g;
+        kf[kb][j][0] = *(const vec8*)(krow);
+        kf[kb][j][1] = *(const vec8*)(krow + 32);
+        kf[kb][j][2] = g < 2 ? *(const vec8*)(krow + 64) : zero8;
+      }
+    };
+    load_k(0, 0);
+#pragma unroll
+    for (int pair = 0; pair < 6; ++pair) {
+      if (pair + 1 < 6) load_k((pair + 1) & 1, pair + 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc = TT::mfma(kf[pair & 1][j][0], qf[0], acc);
+        acc = TT::mfma(kf[pair & 1][j][1], qf[1], acc);
+        acc = TT::mfma(kf[pair & 1][j][2], qf[2], acc);
+        st[pair * 2 + j] = acc;
+      }
     }
     // softmax over the 192 keys of query li (spread over 4 lane groups x 48 registers)
     float m = st[0][0];
@@ -93,15 +140,17 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const typename TT
       for (int r = 0; r < 4; ++r) m = fmaxf(m, st[kt][r]);
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+    const float mneg = -m * scale_log2e;
+    float sum4[4] = {0.f, 0.f, 0.f, 0.f};          // four partial sums: no 48-deep dependent add chain
 #pragma unroll
     for (int kt = 0; kt < 12; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f((st[kt][r] - m) * scale_log2e);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], scale_log2e, mneg));
         st[kt][r] = p;
-        sum += p;
+        sum4[r] += p;
       }
+    float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
@@ -116,41 +165,101 @@ __global__ __launch_bounds__(256, 2) void vit_attention_kernel(const typename TT
         pf[kk][4 + r] = (elem)st[2 * kk + 1][r];
       }
 
-    // O^T = V^T . P^T : lane holds O[query li][d = dt*16 + 4g + r]
-    elem* orow = out + ((size_t)b * T + q) * C + h * HD;
+    // O^T = V^T . P^T : lane holds O[query li][d = dt*16 + 4g + r].  Five independent accumulators (one per 16
+    // head-dim columns), V fragments of the next 32 keys in flight while this k-step's MFMAs run.
+    // this lane's address inside the 4-key x 16-column block of its lane group: key 4g + (li>>2), column 4*(li&3)
+    const elem* vblk = Vs + (4 * g + (li >> 2)) * VSTR + 4 * (li & 3);
+    vec4 vlo[2][5], vhi[2][5];
+    auto load_v = [&](int vb, int kk) {
 #pragma unroll
-    for (int dt = 0; dt < 5; ++dt) {
-      // this lane's address inside the 4-key x 16-column block of its lane group: key 4g + (li>>2), column 4*(li&3)
-      const elem* vblk = Vs + (4 * g + (li >> 2)) * VSTR + dt * 16 + 4 * (li & 3);
-      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int dt = 0; dt < 5; ++dt) {
+        vlo[vb][dt] = lds_read_tr4<vec4>(vblk + (32 * kk) * VSTR + dt * 16);        // keys 32kk + 4g .. +3, column dt*16 + li
+        vhi[vb][dt] = lds_read_tr4<vec4>(vblk + (32 * kk + 16) * VSTR + dt * 16);   // keys 32kk + 16 + 4g .. +3
+      }
+    };
+    f32x4_t oacc[5];
 #pragma unroll
-      for (int kk = 0; kk < 6; ++kk) {
-        const vec4 lo = lds_read_tr4<vec4>(vblk + (32 * kk) * VSTR);         // keys 32kk + 4g .. +3, column dt*16 + li
-        const vec4 hi = lds_read_tr4<vec4>(vblk + (32 * kk + 16) * VSTR);    // keys 32kk + 16 + 4g .. +3
+    for (int dt = 0; dt < 5; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    load_v(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+      if (kk + 1 < 6) load_v((kk + 1) & 1, kk + 1);
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) {
         vec8 vf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { vf[i] = lo[i]; vf[4 + i] = hi[i]; }
-        acc = TT::mfma(vf, pf[kk], acc);
+        for (int i = 0; i < 4; ++i) { vf[i] = vlo[kk & 1][dt][i]; vf[4 + i] = vhi[kk & 1][dt][i]; }
+        oacc[dt] = TT::mfma(vf, pf[kk], oacc[dt]);
       }
+    }
+    // through this wave's LDS tile: the accumulator layout gives 8 bytes per lane and 32-byte runs per row; written
+    // from LDS a lane carries 16 bytes and a row leaves as one 160-byte run (3 store instructions instead of 5)
+    elem* ot = (elem*)(smem + 2 * BUF_BYTES + wave * OTILE_BYTES);
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) {
       vec4 o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (elem)(acc[r] * inv);
-      *(vec4*)(orow + dt * 16 + 4 * g) = o;
+      for (int r = 0; r < 4; ++r) o[r] = (elem)(oacc[dt][r] * inv);
+      *(vec4*)(ot + li * HD + dt * 16 + 4 * g) = o;
     }
+    elem* obase = out + ((size_t)b * T + wave * 16) * C + h * HD;
+#pragma unroll
+    for (int c0 = 0; c0 < 16 * (HD / 8); c0 += 64) {
+      const int c = c0 + lane;
+      if (c < 16 * (HD / 8)) {
+        const int row = c / (HD / 8), ch = c % (HD / 8);
+        *(vec8*)(obase + (size_t)row * C + ch * 8) = *(const vec8*)(ot + row * HD + ch * 8);
+      }
+    }
+  };
+
+  // Item loop, unrolled by two so the double buffer and the two Q register sets have fixed roles.  At the top of a
+  // step everything this wave issued a step ago is waited for (K/V copies and Q of the current item; the previous
+  // item's output stores), the barrier then (a) publishes all waves' copies and (b) says every wave is done reading
+  // the other buffer, which the next item's copies overwrite while this item is computed.
+  vec8 qa[3], qb[3];
+  // XCD-aware item order: workgroups b, b+8, .. share an XCD and its L2; give them consecutive items, i.e. all heads of
+  // the same crops at the same time -- a head's rows are 160-byte slices of 7680-byte token rows, so neighbouring heads
+  // share 128-byte lines both in QKV (fetched once per XCD instead of once per head) and in the output (merged in L2)
+  int item = xcd_remap(blockIdx.x, gridDim.x);
+  if (item < items) issue(item, 0, qa);
+  while (item < items) {
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();
+    int nxt = item + gridDim.x;
+    if (nxt < items) issue(nxt, 1, qb);
+    compute(item, 0, qa);
+    item = nxt;
+    if (item >= items) break;
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();
+    nxt = item + gridDim.x;
+    if (nxt < items) issue(nxt, 0, qa);
+    compute(item, 1, qb);
+    item = nxt;
   }
 }
 
 template <class TT>
 int launch_att(const void* qkv, void* out, int B, int heads, float scale, hipStream_t s) {
   static bool attr_set = false;
+  static int n_cu = 0;
   auto kern = vit_attention_kernel<TT>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
       return hm_set_error(HM_ERR_HIP, "hm_vit_attention: cannot raise dynamic LDS limit");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      return hm_set_error(HM_ERR_HIP, "hm_vit_attention: cannot query the device");
+    n_cu = prop.multiProcessorCount;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), ATT_LDS, s, (const typename TT::elem*)qkv,
-                     (typename TT::elem*)out, heads, scale * 1.44269504088896340736f);
+  const int items = B * heads;
+  // persistent: one workgroup per CU, every workgroup the same number of items when items % CUs == 0
+  const int per = (items + n_cu - 1) / n_cu, grid = (items + per - 1) / per;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVE), ATT_LDS, s, (const typename TT::elem*)qkv,
+                     (typename TT::elem*)out, heads, items, scale * 1.44269504088896340736f);
   return hm_check_launch("hm_vit_attention");
 }
 

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   const elem* wsrc[WI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    int gm = m0 + wave * XI * RPI + i * RPI + srow;
+    int gm = (SCHED == 97 ? 0 : m0) + wave * XI * RPI + i * RPI + srow;     // (97: experiment, every tile reads panel 0)
     gm = gm < g.M ? gm : g.M - 1;                          // edge rows: valid memory, never stored
     if (CONV) {
       const int hw = g.Hout * g.Wout;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   }
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
-    int gn = n0 + wave * WI * RPI + i * RPI + srow;
+    int gn = (SCHED == 97 ? 0 : n0) + wave * WI * RPI + i * RPI + srow;
     gn = gn < g.N ? gn : g.N - 1;
     wsrc[i] = W + (size_t)gn * g.ldw + chunk * 8;
     if (SCHED >= 94)
@@ -493,6 +493,7 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
     case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
+    case 18: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 97>(g, s, "hm_gemm"); // EXPERIMENT (wrong results): every tile loads operand panel 0 (pure L2 hits)
     case 16: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 94>(g, s, "hm_gemm"); // EXPERIMENT: fill only, tile-major operands
     case 17: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 95>(g, s, "hm_gemm"); // EXPERIMENT: full kernel, tile-major operands
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
