@@ -62,20 +62,20 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 
 constexpr int CA_MAXT = 256;
 
+// One wavefront (= one workgroup, so all 256 CUs get work at B = 64) per (hand, head); dim_head = 64.  Scores: lane
+// = token (3 tokens per lane), the token's 128-byte K row against q held in LDS.  Output: lane = channel, tokens
+// walked 8 at a time into 4 independent accumulators (the 192-deep dependent FMA chain was most of the old 32 us).
 template <class E>
-__global__ __launch_bounds__(256) void cross_attention_kernel(const float* __restrict__ q, const E* __restrict__ kv,
-                                                              int ldkv, int k_off, int v_off, float* __restrict__ out,
-                                                              int B, int tokens, int heads, float scale) {
-  // one wave per (hand, head); dim_head = 64 = one lane per output channel
-  __shared__ float ps[4][CA_MAXT];
-  __shared__ float qs[4][64];
+__global__ __launch_bounds__(64) void cross_attention_kernel(const float* __restrict__ q, const E* __restrict__ kv,
+                                                             int ldkv, int k_off, int v_off, float* __restrict__ out,
+                                                             int B, int tokens, int heads, float scale) {
+  __shared__ float ps[CA_MAXT];
+  __shared__ float qs[64];
   typedef __attribute__((ext_vector_type(8))) E vec8;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pair = blockIdx.x * 4 + wave;
-  const bool active = pair < B * heads;
-  const int b = active ? pair / heads : 0, h = active ? pair % heads : 0;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int inner = heads * 64;
-  qs[wave][lane] = q[(size_t)b * inner + h * 64 + lane];
+  qs[lane] = q[(size_t)b * inner + h * 64 + lane];
   __syncthreads();
   const E* kbase = kv + (size_t)b * tokens * ldkv + k_off + h * 64;
   const E* vbase = kv + (size_t)b * tokens * ldkv + v_off + h * 64;
@@ -87,14 +87,18 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float* __res
     sc[i] = -3.0e38f;
     if (t < tokens) {
       const E* kr = kbase + (size_t)t * ldkv;
-      float d = 0.f;
+      vec8 kk[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const vec8 kk = *(const vec8*)(kr + c * 8);
+      for (int c = 0; c < 8; ++c) kk[c] = *(const vec8*)(kr + c * 8);
+      float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d = fmaf(qs[wave][c * 8 + e], (float)kk[e], d);
-      }
-      sc[i] = d * scale;
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          d0 = fmaf(qs[c * 8 + e], (float)kk[c][e], d0);
+          d1 = fmaf(qs[c * 8 + e + 1], (float)kk[c][e + 1], d1);
+        }
+      sc[i] = (d0 + d1) * scale;
       mx = fmaxf(mx, sc[i]);
     }
   }
@@ -105,15 +109,23 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float* __res
     const int t = lane + 64 * i;
     if (t < tokens) {
       const float p = __expf(sc[i] - mx);
-      ps[wave][t] = p;
+      ps[t] = p;
       sum += p;
     }
   }
   sum = wave_sum(sum);
   __syncthreads();
-  float o = 0.f;
-  for (int t = 0; t < tokens; ++t) o = fmaf(ps[wave][t], (float)vbase[(size_t)t * ldkv + lane], o);
-  if (active) out[(size_t)b * inner + h * 64 + lane] = o / sum;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  int t = 0;
+  for (; t + 8 <= tokens; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)vbase[(size_t)(t + j) * ldkv + lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j & 3] = fmaf(ps[t + j], v[j], o[j & 3]);
+  }
+  for (; t < tokens; ++t) o[0] = fmaf(ps[t], (float)vbase[(size_t)t * ldkv + lane], o[0]);
+  out[(size_t)b * inner + h * 64 + lane] = ((o[0] + o[1]) + (o[2] + o[3])) / sum;
 }
 
 __global__ void split_head_kernel(const float* __restrict__ head, int ldh, float* __restrict__ pose6d,
@@ -151,7 +163,7 @@ extern "C" int hm_cross_attention(const float* q, const void* kv, int ldkv, int 
     return hm_set_error(HM_ERR_ARG, "hm_cross_attention: dim_head must be 64 and tokens <= 256");
   if (ldkv % 8 != 0 || k_off % 8 != 0 || v_off % 8 != 0 || ((uintptr_t)kv & 15))
     return hm_set_error(HM_ERR_ARG, "hm_cross_attention: kv rows must be 16-byte aligned");
-  dim3 grid((B * heads + 3) / 4), block(256);
+  dim3 grid(B * heads), block(64);
   hipStream_t s = (hipStream_t)stream_;
   HmProfScope prof(HM_K_CROSS_ATTN, 0, B, tokens, heads, s);
   if (dtype == HM_DTYPE_BF16)

@@ -1,14 +1,17 @@
 // rot6d_to_rotmat (geometry.py:47-70) + MANO forward (mano_wrapper.py:32-44 -> smplx.lbs.lbs,
 // same arithmetic as the in-tree manopth layer, manolayer.py:172-262) + camera translation and
-// 2-D projection (hamer.py:131-154), fused: one workgroup per hand, everything per-hand lives
-// in LDS (22 KB); the ~1.4 MB of model parameters are read through L2 (shared by all hands).
-// HBM/L2-bound fp32 work, ~1 MFLOP per hand.
+// 2-D projection (hamer.py:131-154), fused.  L2-bound fp32 work, ~1 MFLOP per hand, dominated by the
+// 1.26 MB of pose blend shapes: NCHUNK workgroups per hand, each repeats the cheap shape / joint /
+// kinematic-chain part (everything per-hand lives in LDS, 22 KB) and then poses and skins only its
+// quarter of the vertices, so a workgroup streams 0.3 MB of posedirs instead of all of it and a
+// batch of 64 hands fills the 256 CUs (one workgroup per hand: 150 us; this form: see DESIGN.md).
 #include "common.h"
 #include "hamer_hip_internal.h"
 
 namespace {
 
 constexpr int MAXV = 800;   // >= 778 vertices
+constexpr int NCHUNK = 4;   // workgroups per hand (vertex ranges)
 __constant__ int c_parents[16] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14};
 __constant__ int c_tips[5] = {744, 320, 443, 554, 671};                       // mano_wrapper.py:23
 __constant__ int c_joint_map[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
@@ -19,7 +22,7 @@ __global__ __launch_bounds__(256) void mano_kernel(hm_mano_model mm, const float
                                                    float* __restrict__ joints, float* __restrict__ cam_t,
                                                    float* __restrict__ kp2d, float focal, float image_size) {
   __shared__ float vs[MAXV * 3];     // v_shaped
-  __shared__ float vp[MAXV * 3];     // v_posed
+  __shared__ float vp[MAXV * 3];     // v_posed (this workgroup's vertex range only)
   __shared__ float Rm[16 * 9];
   __shared__ float Jr[16 * 3];
   __shared__ float pf[136];
@@ -28,8 +31,9 @@ __global__ __launch_bounds__(256) void mano_kernel(hm_mano_model mm, const float
   __shared__ float src[21 * 3];      // 16 posed joints + 5 finger tips
   __shared__ float bt[10];
 
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / NCHUNK, chunk = blockIdx.x % NCHUNK, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = mm.n_verts;
+  const int vper = (V + NCHUNK - 1) / NCHUNK, v0 = chunk * vper, v1 = min(V, v0 + vper);   // this workgroup's vertices
 
   if (tid < 16) {   // rot6d -> rotation matrix, columns (b1, b2, b1 x b2)
     const float* x = pose6d + (size_t)b * 96 + tid * 6;
@@ -46,8 +50,10 @@ __global__ __launch_bounds__(256) void mano_kernel(hm_mano_model mm, const float
     R[3] = b1y; R[4] = b2y; R[5] = b3y;
     R[6] = b1z; R[7] = b2z; R[8] = b3z;
     float* ro = rotmats + ((size_t)b * 16 + tid) * 9;
+    if (chunk == 0) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) ro[i] = R[i];
+      for (int i = 0; i < 9; ++i) ro[i] = R[i];
+    }
   }
   if (tid >= 64 && tid < 74) bt[tid - 64] = betas[(size_t)b * 10 + (tid - 64)];
   __syncthreads();
@@ -74,11 +80,17 @@ __global__ __launch_bounds__(256) void mano_kernel(hm_mano_model mm, const float
     a = wave_sum(a);
     if (lane == 0) Jr[o] = a;
   }
-  // pose blend shapes: v_posed = v_shaped + pose_feature . posedirs
-  for (int o = tid; o < 3 * V; o += 256) {
-    float a = 0.f;
-    for (int p = 0; p < 135; ++p) a = fmaf(pf[p], mm.posedirs[(size_t)p * 3 * V + o], a);
-    vp[o] = vs[o] + a;
+  // pose blend shapes: v_posed = v_shaped + pose_feature . posedirs (three independent chains, 9 loads in flight)
+  for (int o = 3 * v0 + tid; o < 3 * v1; o += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float* pd = mm.posedirs + o;
+#pragma unroll 5
+    for (int p = 0; p < 135; p += 3) {
+      a0 = fmaf(pf[p], pd[(size_t)p * 3 * V], a0);
+      a1 = fmaf(pf[p + 1], pd[(size_t)(p + 1) * 3 * V], a1);
+      a2 = fmaf(pf[p + 2], pd[(size_t)(p + 2) * 3 * V], a2);
+    }
+    vp[o] = vs[o] + ((a0 + a1) + a2);
   }
   __syncthreads();
 
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void mano_kernel(hm_mano_model mm, const float
   __syncthreads();
 
   // linear blend skinning
-  for (int v = tid; v < V; v += 256) {
+  for (int v = v0 + tid; v < v1; v += 256) {
     float Tm[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) Tm[e] = 0.f;
@@ -149,14 +161,17 @@ __global__ __launch_bounds__(256) void mano_kernel(hm_mano_model mm, const float
   }
   __syncthreads();
 
-  if (tid < 21) {   // joint reorder, camera translation, projection
-    const int s = c_joint_map[tid];
+  // joint reorder, camera translation, projection: the 16 chain joints by the hand's first workgroup, a finger tip by
+  // the workgroup that skinned its vertex
+  const int s_ = tid < 21 ? c_joint_map[tid] : 0;
+  if (tid < 21 && (s_ < 16 ? chunk == 0 : (c_tips[s_ - 16] >= v0 && c_tips[s_ - 16] < v1))) {
+    const int s = s_;
     const float jx = src[s * 3 + 0], jy = src[s * 3 + 1], jz = src[s * 3 + 2];
     float* jo = joints + ((size_t)b * 21 + tid) * 3;
     jo[0] = jx; jo[1] = jy; jo[2] = jz;
     const float c0 = cam[(size_t)b * 3 + 0], c1 = cam[(size_t)b * 3 + 1], c2 = cam[(size_t)b * 3 + 2];
     const float tz = 2.0f * focal / (image_size * c0 + 1e-9f);
-    if (tid == 0) { cam_t[(size_t)b * 3 + 0] = c1; cam_t[(size_t)b * 3 + 1] = c2; cam_t[(size_t)b * 3 + 2] = tz; }
+    if (tid == 0 && chunk == 0) { cam_t[(size_t)b * 3 + 0] = c1; cam_t[(size_t)b * 3 + 1] = c2; cam_t[(size_t)b * 3 + 2] = tz; }
     const float px = jx + c1, py = jy + c2, pz = jz + tz;
     const float f = focal / image_size;
     kp2d[((size_t)b * 21 + tid) * 2 + 0] = (px / pz) * f;
@@ -176,7 +191,7 @@ extern "C" int hm_mano_forward(const hm_mano_model* model, const float* pose6d, 
   if (!model->v_template || !model->shapedirs || !model->posedirs || !model->J_regressor || !model->lbs_weights)
     return hm_set_error(HM_ERR_ARG, "hm_mano_forward: incomplete model");
   HmProfScope prof(HM_K_MANO, 0, B, model->n_verts, 0, (hipStream_t)stream_);
-  hipLaunchKernelGGL(mano_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream_, *model, pose6d, betas, cam, rotmats, verts,
+  hipLaunchKernelGGL(mano_kernel, dim3(B * NCHUNK), dim3(256), 0, (hipStream_t)stream_, *model, pose6d, betas, cam, rotmats, verts,
                      joints, cam_t, kp2d, focal_length, image_size);
   return hm_check_launch("hm_mano_forward");
 }
