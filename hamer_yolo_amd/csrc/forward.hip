@@ -11,8 +11,21 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, total;
+  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, partials, total;
+  int ksplit_proj, ksplit_fc2;
 };
+
+// K ranges for x += X.W^T at small M: as many as fill the 256 CUs with 128x128 tiles, whole 64-deep K tiles per range.
+// proj / fc2 at 4 hands: 60 tiles x 20 / 80 K-steps on 60 CUs -> 240 workgroups x 5 / 20 K-steps.
+int pick_split_k(int M, int N, int K) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128), nk = K / 64;
+  if (M >= 1024 || N < 512 || K % 64 != 0 || tiles * 2 > 256) return 1;     // M < 1024: hm_gemm's 128x128 tile
+  int want = 256 / tiles;
+  if (want > 8) want = 8;                               // the consumer reads every slab: diminishing returns
+  if (want > nk) want = nk;
+  while (want > 1 && nk % want != 0) --want;
+  return want;
+}
 
 Layout make_layout(const hm_hamer_weights& w, int B) {
   const int gh = (w.img_h + 2 * w.pad - w.patch) / w.patch + 1, gw = (w.win_w + 2 * w.pad - w.patch) / w.patch + 1;
@@ -35,6 +48,11 @@ Layout make_layout(const hm_hamer_weights& w, int B) {
   L.head = o; o += align256((size_t)B * 112 * 4);
   L.stats = o; o += align256(M * ((D + 63) / 64) * 8);      // deferred-LN partials [D/64][M][2]
   L.rowstats = o; o += align256(M * 8);                      // (mean, rstd) per row
+  // split-K of the two N = D GEMMs of a block when their 128x128 tiles would leave most CUs idle (a few hands)
+  L.ksplit_proj = pick_split_k((int)M, (int)D, (int)D);
+  L.ksplit_fc2 = pick_split_k((int)M, (int)D, w.mlp_dim);
+  const int smax = L.ksplit_proj > L.ksplit_fc2 ? L.ksplit_proj : L.ksplit_fc2;
+  L.partials = o; o += smax > 1 ? align256((size_t)smax * M * D * 4) : 0;
   L.total = o;
   return L;
 }
@@ -90,6 +108,21 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
     if (epi == HM_EPI_RESID_LN) return hm_ln_finalize(stats, rowstats, M, N, w->vit_eps, stream);
     return HM_OK;
   };
+  // x += X.W^T + b followed by LayerNorm(x) -> h (or tok): one residual GEMM + LayerNorm, or, for a few hands, a
+  // split-K GEMM into partial slabs and a LayerNorm that adds them (hm_layernorm_accum)
+  float* partials = (float*)(ws + L.partials);
+  auto resid_gemm_ln = [&](const void* X, int K, const void* W, const float* bias, int ksplit, const float* ln_g,
+                           const float* ln_b, void* ln_out) {
+    if (ksplit > 1) {
+      hm_gemm_args g{};
+      g.X = X; g.W = W; g.C = partials; g.M = M; g.N = D; g.K = K; g.ldx = K; g.ldw = K; g.ldc = D;
+      g.epilogue = HM_EPI_F32; g.dtype = dt; g.k_split = ksplit;
+      HM_TRY(hm_gemm(&g, stream));
+      return hm_layernorm_accum(x, partials, ksplit, bias, ln_g, ln_b, ln_out, dt, M, D, w->vit_eps, stream);
+    }
+    HM_TRY(gemm(X, K, W, K, D, x, D, bias, HM_EPI_RESID_F32, x, D, 0));
+    return hm_layernorm(x, ln_g, ln_b, ln_out, dt, M, D, w->vit_eps, stream);
+  };
   bool fold = D % 64 == 0 && w->depth > 0;
   for (int i = 0; i < w->depth && fold; ++i) {
     const hm_vit_block& b = w->blocks[i];
@@ -99,6 +132,7 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
   // ---- ViT backbone (vit.py:320-339)
   HM_TRY(hm_patch_im2col(img, ws + L.patches, B, w->img_h, w->img_w_full, w->win_x0, w->win_w, w->patch, w->pad, dt, stream));
   const float scale = 1.0f / sqrtf((float)(D / w->heads));
+  void* tok = out->tokens ? out->tokens : h;
   if (fold) HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_LN, w->pos, D, tokens, w->blocks[0].ln1_g));
   else HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
   for (int i = 0; i < w->depth; ++i) {
@@ -111,19 +145,20 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
       if (i + 1 < w->depth) HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_LN, x, D, 0, w->blocks[i + 1].ln1_g));
       else HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, D, 0));   // last_norm stays a kernel
     } else {
-      HM_TRY(hm_layernorm(x, b.ln1_g, b.ln1_b, h, dt, M, D, w->vit_eps, stream));
+      // the LayerNorm that follows each residual GEMM is issued with it: LN1 of block i+1 (or last_norm) after fc2
+      if (i == 0) HM_TRY(hm_layernorm(x, b.ln1_g, b.ln1_b, h, dt, M, D, w->vit_eps, stream));
       HM_TRY(gemm(h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
       HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
-      HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, D, 0));
-      HM_TRY(hm_layernorm(x, b.ln2_g, b.ln2_b, h, dt, M, D, w->vit_eps, stream));
+      HM_TRY(resid_gemm_ln(att, D, b.proj_w, b.proj_b, L.ksplit_proj, b.ln2_g, b.ln2_b, h));
       HM_TRY(gemm(h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0));
-      HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, D, 0));
+      const bool last = i + 1 == w->depth;
+      HM_TRY(resid_gemm_ln(mlp, w->mlp_dim, b.fc2_w, b.fc2_b, L.ksplit_fc2, last ? w->last_g : w->blocks[i + 1].ln1_g,
+                           last ? w->last_b : w->blocks[i + 1].ln1_b, last ? tok : h));
     }
     if (i == 0 && after_first_block && hipEventRecord(after_first_block, (hipStream_t)stream) != hipSuccess)
       return hm_set_error(HM_ERR_HIP, "hm_hamer_forward_split: hipEventRecord failed");
   }
-  void* tok = out->tokens ? out->tokens : h;
-  HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
+  if (fold) HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
 
   // ---- decoder head (mano_head.py:61-95, pose_transformer.py:191-201)
   const int dim = w->dec_dim, inner = w->dec_heads * w->dec_dim_head, ldkv = w->dec_depth * 2 * inner;

@@ -30,6 +30,7 @@ struct KArgs {                                    // kernel-side view of either 
   // deferred LayerNorm (HM_EPI_RESID_LN produces, HM_EPI_LN_STORE / HM_EPI_LN_GELU consume)
   const float* ln_gamma; void* ln_xg; float* ln_stats; const float* ln_colsum;
   int ln_P;
+  int ksplit;                                     // HM_EPI_F32 only: K is cut into ksplit ranges, one workgroup and one [M][ldc] slab of C each
   // convolution geometry (CONV only)
   const void* zeros;
   int H, Wd, Hout, Wout, ksz, stride, pad, cin_log2, taps;
@@ -106,7 +107,7 @@ __device__ __forceinline__ float row8_sum(float v) {
 
 template <class T, int EPI, int MI, int NI>
 __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI], int mb, int nb, int lane, char* wlds,
-                                         const float2* rowstat, const float* cbias, const float* cvec2) {
+                                         const float2* rowstat, const float* cbias, const float* cvec2, int split) {
   using elem = typename T::elem;
   // n-subtiles per column group: <= 16 KB of LDS per wave; the residual epilogue splits that between the
   // transposed accumulators and the residual rows, which arrive by LDS-DMA (no registers, all in flight at once)
@@ -249,7 +250,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         if (RES) {
           *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v + r;
         } else if (EPI == HM_EPI_F32) {
-          *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v;
+          *(f32x4_t*)((float*)g.C + ((size_t)split * g.M + m) * g.ldc + n) = v;      // split-K: slab `split` of C
         } else {
           typename T::vec4 o;
 #pragma unroll
@@ -283,7 +284,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int wgid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = (EPI == HM_EPI_F32 && !CONV) ? wgid % g.ksplit : 0;   // which K range (split-K: ksplit > 1)
+  tile_coords((EPI == HM_EPI_F32 && !CONV) ? wgid / g.ksplit : wgid, tiles_m, tiles_n, g.group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int wr = wave / WN, wc = wave % WN;
 
@@ -383,7 +386,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   };
 
   // ---- K loop: ring of STAGES buffers, STAGES-1 tiles of LDS-DMA in flight across the barrier
-  const int nk = g.K / BK;
+  const int nk = (EPI == HM_EPI_F32 && !CONV) ? g.K / BK / g.ksplit : g.K / BK;
+  if (EPI == HM_EPI_F32 && !CONV) {                     // this workgroup's K range starts split * nk tiles in
+#pragma unroll
+    for (int i = 0; i < XI; ++i) xsrc[i] += (size_t)split * nk * BK;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wsrc[i] += (size_t)split * nk * BK;
+  }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) stage(s, s);
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   float* colvec = (float*)(rowstat + BM);              // [2][BN]: bias (or zeros) | ln_gamma or ln_colsum
   for (int c = tid; c < BN; c += 64 * NW) {
     const int n = min(n0 + c, g.N - 1);
-    colvec[c] = g.bias ? g.bias[n] : 0.f;
+    colvec[c] = (g.bias && split == 0) ? g.bias[n] : 0.f;
     if constexpr (EPI == HM_EPI_RESID_LN) colvec[BN + c] = g.ln_gamma[n];
     if constexpr (epi_ln_in(EPI)) colvec[BN + c] = g.ln_colsum[n];
   }
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     return;
   }
   epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI),
-                           rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI);
+                           rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI, split);
 }
 
 // partial (sum, sum of squares) per 64 columns [P][M][2] -> (mean, rstd) per row [M][2]
@@ -460,7 +469,7 @@ int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
       return hm_set_error(HM_ERR_HIP, "gemm: cannot raise the dynamic LDS limit");
     attr_set = true;
   }
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * ((EPI == HM_EPI_F32 && !CONV) ? g.ksplit : 1);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, s, g);
   return hm_check_launch(what);
 }
@@ -604,6 +613,12 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
   k.X = g.X; k.W = g.W; k.C = g.C; k.bias = g.bias; k.resid = g.resid;
   k.M = g.M; k.N = g.N; k.K = g.K; k.ldx = g.ldx; k.ldw = g.ldw; k.ldc = g.ldc; k.ldr = g.ldr; k.resid_mod = g.resid_mod;
   k.group_m = g_group_m;
+  k.ksplit = 1;
+  if (g.k_split > 1) {
+    if (g.epilogue != HM_EPI_F32 || g.bias || g.K % (BK_DEFAULT * g.k_split) != 0)
+      return hm_set_error(HM_ERR_ARG, "hm_gemm: k_split needs HM_EPI_F32, no bias and K % (64 * k_split) == 0");
+    k.ksplit = g.k_split;
+  }
   if (ln_out) { k.ln_gamma = g.ln_gamma; k.ln_xg = g.ln_xg; k.ln_stats = g.ln_stats; k.ln_P = g.N / 64; }
   if (ln_in) {
     k.ln_stats = g.ln_stats; k.ln_colsum = g.ln_colsum;

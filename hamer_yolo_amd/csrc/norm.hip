@@ -26,10 +26,13 @@ __device__ __forceinline__ void store4<_Float16>(_Float16* p, f32x4_t v) {
 
 // MAXJ = ceil(D / 256) 16-byte pieces per lane.  The affine parameters are fetched after the reductions: fetching
 // them with the row (15 loads in flight per lane) measured 1.5x SLOWER on MI355X -- the kernel lives on occupancy.
-template <class OutT, int MAXJ>
+// ACC: the residual add of a split-K producer rides along: x[row] += bias + sum_s part[s][row] (s ascending, so the
+// sum has one order whatever the launch), written back before the statistics are taken.
+template <class OutT, int MAXJ, bool ACC = false>
 __global__ __launch_bounds__(256, 8) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, OutT* __restrict__ out, int M,
-                                                        int D, float eps) {
+                                                        int D, float eps, const float* __restrict__ part = nullptr,
+                                                        int n_part = 0, const float* __restrict__ bias = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -40,6 +43,28 @@ __global__ __launch_bounds__(256, 8) void layernorm_kernel(const float* __restri
     const int i = lane * 4 + j * 256;
     v[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (i < D) v[j] = *(const f32x4_t*)(xr + i);
+  }
+  if constexpr (ACC) {
+    f32x4_t a[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = lane * 4 + j * 256;
+      a[j] = (bias && i < D) ? *(const f32x4_t*)(bias + i) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 2
+    for (int s = 0; s < n_part; ++s) {             // slab by slab: the MAXJ loads of a slab are in flight together
+      const float* pr = part + ((size_t)s * M + row) * D;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int i = lane * 4 + j * 256;
+        if (i < D) a[j] += *(const f32x4_t*)(pr + i);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = lane * 4 + j * 256;
+      if (i < D) { v[j] += a[j]; *(f32x4_t*)(const_cast<float*>(xr) + i) = v[j]; }
+    }
   }
   float s = 0.f;
 #pragma unroll
@@ -94,6 +119,30 @@ extern "C" int hm_layernorm(const float* x, const float* gamma, const float* bet
   else if (out_dtype == HM_OUT_F32) launch_ln<float>(x, gamma, beta, (float*)out, M, D, eps, s);
   else return hm_set_error(HM_ERR_ARG, "hm_layernorm: bad out_dtype");
   return hm_check_launch("hm_layernorm");
+}
+
+template <class OutT>
+void launch_ln_acc(float* x, const float* part, int n_part, const float* bias, const float* g, const float* b, OutT* out, int M,
+                   int D, float eps, hipStream_t s) {
+  dim3 grid((M + 3) / 4), block(256);
+  const int mj = (D + 255) / 256;
+  if (mj <= 2) hipLaunchKernelGGL((layernorm_kernel<OutT, 2, true>), grid, block, 0, s, x, g, b, out, M, D, eps, part, n_part, bias);
+  else if (mj <= 5) hipLaunchKernelGGL((layernorm_kernel<OutT, 5, true>), grid, block, 0, s, x, g, b, out, M, D, eps, part, n_part, bias);
+  else hipLaunchKernelGGL((layernorm_kernel<OutT, 8, true>), grid, block, 0, s, x, g, b, out, M, D, eps, part, n_part, bias);
+}
+
+extern "C" int hm_layernorm_accum(float* x, const float* partials, int n_partials, const float* bias, const float* gamma,
+                                  const float* beta, void* out, int out_dtype, int M, int D, float eps, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!x || !partials || !gamma || !beta || !out || n_partials <= 0) return hm_set_error(HM_ERR_ARG, "hm_layernorm_accum: null pointer");
+  if (M <= 0 || D <= 0 || D % 4 != 0 || D > 256 * MAXJ_LIMIT)
+    return hm_set_error(HM_ERR_ARG, "hm_layernorm_accum: need 0 < D <= 2048, D % 4 == 0, M > 0");
+  HmProfScope prof(HM_K_LAYERNORM, out_dtype, M, D, n_partials, s);
+  if (out_dtype == HM_DTYPE_BF16) launch_ln_acc<__bf16>(x, partials, n_partials, bias, gamma, beta, (__bf16*)out, M, D, eps, s);
+  else if (out_dtype == HM_DTYPE_F16) launch_ln_acc<_Float16>(x, partials, n_partials, bias, gamma, beta, (_Float16*)out, M, D, eps, s);
+  else if (out_dtype == HM_OUT_F32) launch_ln_acc<float>(x, partials, n_partials, bias, gamma, beta, (float*)out, M, D, eps, s);
+  else return hm_set_error(HM_ERR_ARG, "hm_layernorm_accum: bad out_dtype");
+  return hm_check_launch("hm_layernorm_accum");
 }
 
 extern "C" int hm_broadcast_rows(const float* vec, float* out, int B, int D, void* stream_) {

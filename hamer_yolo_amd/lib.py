@@ -21,7 +21,7 @@ EXPORTS = [
     "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
-    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_hamer_forward_split", "hm_ln_finalize",
+    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_hamer_forward_split", "hm_ln_finalize", "hm_layernorm_accum",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("ldx", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
                 ("resid_mod", C.c_int), ("epilogue", C.c_int), ("dtype", C.c_int),
-                ("ln_gamma", vp), ("ln_xg", vp), ("ln_stats", vp), ("ln_colsum", vp)]
+                ("ln_gamma", vp), ("ln_xg", vp), ("ln_stats", vp), ("ln_colsum", vp), ("k_split", C.c_int)]
 
 
 class ManoModel(C.Structure):
@@ -130,6 +130,7 @@ def load() -> C.CDLL:
     lib.hm_hamer_forward.argtypes = [C.POINTER(HamerWeights), vp, i, C.POINTER(HamerOutputs), vp, C.c_size_t, vp]
     lib.hm_hamer_forward_split.argtypes = [C.POINTER(HamerWeights), vp, i, C.POINTER(HamerOutputs), vp, C.c_size_t, vp, vp, vp, vp]
     lib.hm_ln_finalize.argtypes = [vp, vp, i, i, C.c_float, vp]
+    lib.hm_layernorm_accum.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, C.c_float, vp]
     lib.hm_conv2d_nhwc.argtypes = [C.POINTER(ConvArgs), vp]
     lib.hm_maxpool_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.hm_upsample2x_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]

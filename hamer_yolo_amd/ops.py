@@ -30,7 +30,7 @@ def _dev(*ts):
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = L.HM_EPI_STORE,
          resid: Optional[torch.Tensor] = None, resid_mod: int = 0, out: Optional[torch.Tensor] = None,
          ln_gamma: Optional[torch.Tensor] = None, ln_xg: Optional[torch.Tensor] = None,
-         ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+         ln_stats: Optional[torch.Tensor] = None, ln_colsum: Optional[torch.Tensor] = None, k_split: int = 0) -> torch.Tensor:
     """out = epilogue(x @ w.T + bias); x (M,K), w (N,K) 16-bit row-major.  Deferred LayerNorm: HM_EPI_RESID_LN also
     fills ln_xg (M,N) 16-bit = out * ln_gamma and ln_stats (N/64, M, 2); HM_EPI_LN_STORE / HM_EPI_LN_GELU read
     ln_stats (M, 2) = ln_finalize(partials) and ln_colsum (N,)."""
@@ -44,13 +44,35 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert ln_stats.shape == (N // 64, M, 2) and ln_stats.is_contiguous() and ln_gamma.shape == (N,)
     if epilogue in (L.HM_EPI_LN_STORE, L.HM_EPI_LN_GELU):
         assert ln_stats.shape == (M, 2) and ln_stats.is_contiguous() and ln_colsum.shape == (N,)
+    if k_split > 1:                      # HM_EPI_F32 split-K: out is (k_split, M, N) partial products
+        assert epilogue == L.HM_EPI_F32 and bias is None
+        if out is None:
+            out = torch.empty(k_split, M, N, device=x.device, dtype=torch.float32)
+        assert out.shape == (k_split, M, N) and out.is_contiguous()
+        a = L.GemmArgs(L.ptr(x), L.ptr(w), L.ptr(out), None, None, M, N, K, x.stride(0), w.stride(0), N, 0, 0, epilogue,
+                       _dt(x), None, None, None, None, k_split)
+        L.check(L.load().hm_gemm(C.byref(a), L.current_stream()), "hm_gemm")
+        return out
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32 if f32_out else x.dtype)
     assert out.shape == (M, N) and out.stride(1) == 1
     a = L.GemmArgs(L.ptr(x), L.ptr(w), L.ptr(out), L.ptr(bias), L.ptr(resid), M, N, K, x.stride(0), w.stride(0),
                    out.stride(0), resid.stride(0) if resid is not None else 0, resid_mod, epilogue, _dt(x),
-                   L.ptr(ln_gamma), L.ptr(ln_xg), L.ptr(ln_stats), L.ptr(ln_colsum))
+                   L.ptr(ln_gamma), L.ptr(ln_xg), L.ptr(ln_stats), L.ptr(ln_colsum), 0)
     L.check(L.load().hm_gemm(C.byref(a), L.current_stream()), "hm_gemm")
+    return out
+
+
+def layernorm_accum(x: torch.Tensor, partials: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
+                    beta: torch.Tensor, eps: float, out_dtype=torch.bfloat16) -> torch.Tensor:
+    """x (M,D) f32 += bias + partials.sum(0) in place (partials (S,M,D) from gemm(k_split=S)); returns LayerNorm(x)."""
+    _dev(x, partials, bias, gamma, beta)
+    M, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and partials.shape[1:] == (M, D) and partials.is_contiguous()
+    out = torch.empty(M, D, device=x.device, dtype=out_dtype)
+    code = L.HM_OUT_F32 if out_dtype == torch.float32 else _DT[out_dtype]
+    L.check(L.load().hm_layernorm_accum(L.ptr(x), L.ptr(partials), partials.shape[0], L.ptr(bias), L.ptr(gamma), L.ptr(beta),
+                                        L.ptr(out), code, M, D, eps, L.current_stream()), "hm_layernorm_accum")
     return out
 
 

@@ -60,6 +60,10 @@ typedef struct hm_gemm_args {
   float* ln_stats;        /* RESID_LN: out [N/64][M][2] = (sum, sum of squares) of C per 64 columns;
                              LN_*: in [M][2] = (mean, rstd) per row, made from those by hm_ln_finalize     */
   const float* ln_colsum; /* LN_*: [N] sum_k W[n][k] * gamma[k] over the 16-bit W; bias = b + W.beta      */
+  /* split-K (HM_EPI_F32, bias == NULL): K is cut into k_split ranges computed by separate workgroups; range s
+   * writes its partial product to C + s*M*ldc.  For small M (few output tiles, long K); the consumer adds the
+   * slabs in order (hm_layernorm_accum), so the result is deterministic.  0 or 1: off. */
+  int k_split;
 } hm_gemm_args;
 
 /* nn.Linear forward on MFMA: C = epilogue(X . W^T).  Replaces the aten::addmm calls behind
@@ -80,6 +84,11 @@ int hm_gemm_set_group_m(int group_m);
 #define HM_OUT_F32 2
 int hm_layernorm(const float* x, const float* gamma, const float* beta, void* out, int out_dtype,
                  int M, int D, float eps, void* stream);
+/* The residual add in front of a LayerNorm (Block.forward vit.py:148-151) for a split-K producer:
+ * x[m] += bias + sum_s partials[s][m] (s ascending; partials [n_partials][M][D] f32 from hm_gemm k_split), then
+ * out = LayerNorm(x) as hm_layernorm.  x is updated in place. */
+int hm_layernorm_accum(float* x, const float* partials, int n_partials, const float* bias, const float* gamma,
+                       const float* beta, void* out, int out_dtype, int M, int D, float eps, void* stream);
 
 /* Attention.forward core (vit.py:115-123): softmax(scale q k^T) v for `tokens`=192 keys.
  * qkv [B*tokens][3*heads*head_dim] 16-bit, column = which*H*d + head*d + i (reshape at

@@ -144,6 +144,34 @@ def test_gemm_deferred_layernorm(variant, dt):
         lib.hm_gemm_set_variant(-1)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(192, 1280, 5120, 10), (768, 1280, 1280, 4), (768, 1280, 5120, 4), (100, 320, 320, 5),
+                                     (1000, 640, 448, 7)])
+def test_gemm_split_k_and_layernorm_accum(M, N, K, S):
+    """Small-M residual GEMM as split-K partial slabs + the LayerNorm that adds them (x += X.W^T + b; LN(x)):
+    slabs against fp64 partial products, the accumulated x and its LayerNorm against the single-pass kernels, and
+    bit-reproducible from run to run (fixed summation order, no atomics)."""
+    x = _u("sx", (M, K), 1.0, seed=M).to(torch.bfloat16)
+    w = _u("sw", (N, K), 0.05, seed=N).to(torch.bfloat16)
+    bias, resid = _u("sb", (N,), 0.5, seed=K), _u("sr", (M, N), 1.0, seed=7)
+    gamma, beta = _u("sg", (N,), 0.3, seed=3, center=1.0), _u("sbt", (N,), 0.2, seed=4)
+    parts = ops.gemm(x.to(DEV), w.to(DEV), None, L.HM_EPI_F32, k_split=S)
+    kl = K // S
+    for s_ in range(S):
+        ref = x[:, s_ * kl:(s_ + 1) * kl].double() @ w[:, s_ * kl:(s_ + 1) * kl].double().t()
+        np.testing.assert_allclose(parts[s_].cpu().double().numpy(), ref.numpy(), atol=2e-5 * math.sqrt(kl), rtol=1e-5)
+    xa = resid.to(DEV).clone()
+    h = ops.layernorm_accum(xa, parts, bias.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6)
+    xb = resid.to(DEV).clone()
+    ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), L.HM_EPI_RESID_F32, resid=xb, out=xb)
+    hb = ops.layernorm(xb, gamma.to(DEV), beta.to(DEV), 1e-6)
+    np.testing.assert_allclose(xa.cpu().numpy(), xb.cpu().numpy(), atol=1e-5 * math.sqrt(K), rtol=1e-5)
+    assert (h.float() - hb.float()).abs().max().item() <= 2 * _ulp16(torch.bfloat16) * hb.float().abs().max().item()
+    xa2 = resid.to(DEV).clone()
+    h2 = ops.layernorm_accum(xa2, ops.gemm(x.to(DEV), w.to(DEV), None, L.HM_EPI_F32, k_split=S), bias.to(DEV), gamma.to(DEV),
+                             beta.to(DEV), 1e-6)
+    assert torch.equal(xa, xa2) and torch.equal(h, h2)
+
+
 def test_gemm_rejects_bad_arguments():
     x = torch.zeros(16, 96, device=DEV, dtype=torch.bfloat16)
     w = torch.zeros(16, 96, device=DEV, dtype=torch.bfloat16)
