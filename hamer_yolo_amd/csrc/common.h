@@ -60,6 +60,29 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// MXFP8 block quantisation (OCP e4m3 elements, one E8M0 scale per 32 elements along K).  The scale byte of a block whose
+// largest magnitude is amax is ceil(log2(amax / 448)) + 127, read off the float's exponent field (E8M0 and fp32 share the
+// bias); elements are multiplied by the exact inverse power of two and rounded to e4m3 (RNE), so |element| <= 448.
+__device__ __forceinline__ unsigned mx8_scale_byte(float amax) {
+  const unsigned bits = __float_as_uint(amax * (1.0f / 448.0f));
+  return (bits >> 23) + ((bits & 0x7FFFFFu) != 0u);
+}
+__device__ __forceinline__ float mx8_inv_scale(unsigned sb) { return __uint_as_float((254u - sb) << 23); }
+__device__ __forceinline__ int mx8_pack4(float a, float b, float c, float d) {
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+}
+// max over each aligned group of 4 lanes / 8 lanes on the DPP path
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  return v;
+}
+__device__ __forceinline__ float row8_max(float v) {
+  v = quad_max(v);
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+}
+
 #define HM_OK 0
 #define HM_ERR_ARG (-1)
 #define HM_ERR_HIP (-2)

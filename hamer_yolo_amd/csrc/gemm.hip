@@ -30,6 +30,7 @@ struct KArgs {                                    // kernel-side view of either 
   // deferred LayerNorm (HM_EPI_RESID_LN produces, HM_EPI_LN_STORE / HM_EPI_LN_GELU consume)
   const float* ln_gamma; void* ln_xg; float* ln_stats; const float* ln_colsum;
   int ln_P;
+  const unsigned char* xs; const float* wscale; unsigned char* out_scales;   // hm_gemm_fp8
   int ksplit;                                     // HM_EPI_F32 only: K is cut into ksplit ranges, one workgroup and one [M][ldc] slab of C each
   // convolution geometry (CONV only)
   const void* zeros;
@@ -114,7 +115,8 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
   constexpr int CGN0 = epi_cgn(MI, NI);
   constexpr bool LNOUT = EPI == HM_EPI_RESID_LN, LNIN = epi_ln_in(EPI);
   constexpr bool RES = EPI == HM_EPI_RESID_F32 || LNOUT;
-  constexpr bool ACT_GELU = EPI == HM_EPI_GELU || EPI == HM_EPI_LN_GELU;
+  constexpr bool MX8 = EPI == HM_EPI_GELU_MX8;
+  constexpr bool ACT_GELU = EPI == HM_EPI_GELU || EPI == HM_EPI_LN_GELU || MX8;
   constexpr int CGN = (RES && CGN0 > 1) ? CGN0 / 2 : CGN0;
   constexpr int NCH = CGN * 4;                     // 16-byte chunks per staged row (4, 8 or 16)
   constexpr int RS = NCH * 16;                     // staged row stride in bytes
@@ -155,7 +157,8 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
       }
     if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // LDS -> row-major, bias / activation / residual, coalesced stores
-    if constexpr ((EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU || LNIN) && NCH >= 8) {
+    if constexpr ((EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU || LNIN || MX8) && NCH >= 8) {
+      static_assert(!MX8 || NCH == 16, "MXFP8 output: 8 lanes per row, 4 lanes per 32-column scale block");
       // 16-bit outputs: 8 columns (two staged chunks) per lane -> one 16-byte store, NCH/2 lanes per row
       constexpr int LPR = NCH / 2, RPI2 = 64 / LPR, ITS2 = MI * 16 / RPI2;
       const int row0 = lane / LPR, j = lane % LPR;
@@ -174,6 +177,21 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         if (m >= g.M || n >= g.N) continue;
         if (LNIN) { v0 = (v0 - st.x * cs0) * st.y; v1 = (v1 - st.x * cs1) * st.y; }
         v0 += bi0; v1 += bi1;
+        if constexpr (MX8) {
+          // MXFP8 out: this lane's 8 columns and its 3 quad neighbours' form one 32-column block of row m (N % 64 == 0,
+          // so a row's lanes are all in or all out: the quad reduction sees no inactive lane)
+          float amax = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v0[q] = gelu_fast(v0[q]); v1[q] = gelu_fast(v1[q]); amax = fmaxf(amax, fmaxf(fabsf(v0[q]), fabsf(v1[q]))); }
+          const unsigned sb = mx8_scale_byte(quad_max(amax));
+          const float inv = mx8_inv_scale(sb);
+          int2 o8;
+          o8.x = mx8_pack4(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);
+          o8.y = mx8_pack4(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
+          *(int2*)((char*)g.C + (size_t)m * g.ldc + n) = o8;
+          if ((j & 3) == 0) g.out_scales[(size_t)(n >> 5) * g.M + m] = (unsigned char)sb;
+          continue;
+        }
         typename T::vec8 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -445,6 +463,152 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
                            rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI, split);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// hm_gemm_fp8: the same 256x256 tile, 8 waves (4x2, each 64x128), 2-stage LDS-DMA ring, on the block-scaled fp8 MFMA
+// v_mfma_scale_f32_16x16x128_f8f6f4.  A K-step is 128 e4m3 bytes per row -- the byte geometry (128-byte rows, 16-byte
+// chunk XOR swizzle, 64 KB per stage) is that of the 16-bit kernel at BK = 64, but a stage now carries twice the K
+// and its 32 MFMAs per wave (2x the cycles each) four times the flops of a 16-bit sub-step.
+// Operand lane map (probed with exact data, tools/probes/): lane (r = l & 15, g = l >> 4) holds, for row r, the 16 bytes
+// k = 16g .. 16g+15 in VGPRs 0-3 and k = 64+16g .. 64+16g+15 in VGPRs 4-7, i.e. 16-byte chunks g and 4+g of the
+// 128-byte row; the E8M0 scale byte supplied by lane (r, g) scales k = 32g .. 32g+31 of row r.  MFMA "A" = W rows
+// (scale 1.0: W carries one f32 scale per output channel, applied to the accumulators), "B" = X rows with their
+// MXFP8 block scales, which travel with the stage: [4 k-blocks][256 rows] bytes = one more 1-KiB LDS-DMA per K-step.
+typedef __attribute__((ext_vector_type(8))) int v8i_t;
+typedef __attribute__((ext_vector_type(4))) int v4i_t;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const KArgs g) {
+  constexpr int WM = 4, WN = 2, MI = 4, NI = 8, NW = 8, BM = 256, BN = 256, BKB = 128;
+  constexpr int TILE_BYTES = 256 * BKB, SCALE_BYTES = 4 * BM, STAGE_BYTES = 2 * TILE_BYTES + SCALE_BYTES;
+  constexpr int XI = BM / NW / 8, WI = BN / NW / 8;              // 1-KiB DMA pieces (8 rows) per wave and operand: 4 + 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wr = wave / WN, wc = wave % WN;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+
+  const int srow = lane >> 3, chunk = (lane & 7) ^ (srow & 7);
+  const char* xsrc[XI];
+  const char* wsrc[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    int gm = m0 + wave * XI * 8 + i * 8 + srow;
+    gm = gm < g.M ? gm : g.M - 1;
+    xsrc[i] = X + (size_t)gm * g.ldx + chunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int gn = n0 + wave * WI * 8 + i * 8 + srow;
+    gn = gn < g.N ? gn : g.N - 1;
+    wsrc[i] = W + (size_t)gn * g.ldw + chunk * 16;
+  }
+  // scales of a K-step: lane l copies the 16 row-scales [m0 + 16*(l&15), +16) of k-block l>>4 (rows past M: clamped)
+  int srow0 = m0 + 16 * (lane & 15);
+  srow0 = srow0 + 16 <= g.M ? srow0 : g.M - 16;
+  const unsigned char* ssrc = g.xs + (size_t)(lane >> 4) * g.M + srow0;
+
+  auto stage = [&](int buf, int kt) {
+    char* lx = smem + buf * STAGE_BYTES + wave * XI * 1024;
+    char* lw = smem + buf * STAGE_BYTES + TILE_BYTES + wave * WI * 1024;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) glds16(xsrc[i] + (size_t)kt * BKB, lx + i * 1024);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) glds16(wsrc[i] + (size_t)kt * BKB, lw + i * 1024);
+    if (wave == 0) glds16(ssrc + (size_t)kt * 4 * g.M, smem + buf * STAGE_BYTES + 2 * TILE_BYTES);
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+  const int c_lo = ((fg ^ fsw) * 16), c_hi = (((4 + fg) ^ fsw) * 16);
+  auto kstep = [&](int buf) {
+    const char* lx = smem + buf * STAGE_BYTES;
+    const char* lw = lx + TILE_BYTES;
+    const unsigned char* ls = (const unsigned char*)(lx + 2 * TILE_BYTES) + fg * BM + wr * 64 + frow;
+    v8i_t xf[MI];
+    int xsc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const char* r = lx + (wr * 64 + i * 16 + frow) * BKB;
+      const v4i_t lo = *(const v4i_t*)(r + c_lo), hi = *(const v4i_t*)(r + c_hi);
+      xf[i] = v8i_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      xsc[i] = ls[i * 16];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // two halves of the wave's 128 columns: 4 W fragments live at a time
+      v8i_t wf[NI / 2];
+#pragma unroll
+      for (int i = 0; i < NI / 2; ++i) {
+        const char* r = lw + (wc * 128 + (h * 4 + i) * 16 + frow) * BKB;
+        const v4i_t lo = *(const v4i_t*)(r + c_lo), hi = *(const v4i_t*)(r + c_hi);
+        wf[i] = v8i_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NI / 2; ++i)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[h * 4 + i][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], xf[mi], acc[h * 4 + i][mi], 0, 0, 0, 127, 0, xsc[mi]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  const int nk = g.K / BKB;
+  stage(0, 0);
+  constexpr int RING_BYTES = 2 * STAGE_BYTES;
+  float2* rowstat = (float2*)(smem + RING_BYTES);                 // unused here, keeps the epilogue's LDS map
+  float* colvec = (float*)(rowstat + BM);
+  for (int c = tid; c < BN; c += 512) {
+    const int n = min(n0 + c, g.N - 1);
+    colvec[c] = g.bias ? g.bias[n] : 0.f;
+    colvec[BN + c] = g.wscale[n];
+  }
+  int rd = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) stage(rd ^ 1, kt + 1);
+    kstep(rd);
+    rd ^= 1;
+  }
+  __builtin_amdgcn_s_barrier();
+  // per-output-channel weight scale: lane's 4 accumulator registers of tile ni are columns ni*16 + 4*(lane>>4) .. +3
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const f32x4_t ws = *(const f32x4_t*)(colvec + BN + wc * 128 + ni * 16 + 4 * fg);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[ni][mi] *= ws;
+  }
+  __builtin_amdgcn_s_barrier();                                   // (the ring is reused as epilogue staging)
+  epilogue<TBf16, EPI, MI, NI>(g, acc, m0 + wr * 64, n0 + wc * 128, lane, smem + wave * epi_stage_bytes(MI, NI),
+                               rowstat + wr * 64, colvec + wc * 128, colvec + BN + wc * 128, 0);
+}
+
+template <int EPI>
+int launch_fp8(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 2 * (2 * 256 * 128 + 4 * 256) + 256 * 8 + 256 * 8;
+  static_assert(LDS >= 8 * epi_stage_bytes(4, 8), "epilogue staging fits in the ring");
+  auto kern = gemm_fp8_kernel<EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return hm_set_error(HM_ERR_HIP, "hm_gemm_fp8: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, g);
+  return hm_check_launch("hm_gemm_fp8");
+}
+
 // partial (sum, sum of squares) per 64 columns [P][M][2] -> (mean, rstd) per row [M][2]
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ fin, int M, int P,
                                                           float invD, float eps) {
@@ -627,6 +791,37 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
   if (g.dtype == HM_DTYPE_BF16) return launch_gemm_epi<TBf16>(k, g.epilogue, stream);
   if (g.dtype == HM_DTYPE_F16) return launch_gemm_epi<TF16>(k, g.epilogue, stream);
   return hm_set_error(HM_ERR_ARG, "hm_gemm: dtype must be HM_DTYPE_BF16 or HM_DTYPE_F16");
+}
+
+extern "C" int hm_gemm_fp8(const hm_gemm_fp8_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!a) return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: null args");
+  const hm_gemm_fp8_args& g = *a;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % 16 != 0 || g.N % 64 != 0 || g.K % 128 != 0)
+    return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: need M % 16 == 0, N % 64 == 0, K % 128 == 0");
+  if (!g.X8 || !g.x_scales || !g.W8 || !g.w_scale || !g.C) return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: null operand");
+  if (g.ldx % 16 != 0 || g.ldw % 16 != 0 || g.ldx < g.K || g.ldw < g.K || g.ldc < g.N || g.ldc % 8 != 0)
+    return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: ldx/ldw must be multiples of 16 bytes covering K, ldc % 8 == 0 covering N");
+  if (((uintptr_t)g.X8 | (uintptr_t)g.x_scales | (uintptr_t)g.W8 | (uintptr_t)g.w_scale | (uintptr_t)g.C | (uintptr_t)g.bias |
+       (uintptr_t)g.resid | (uintptr_t)g.out_scales) & 15)
+    return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: pointers must be 16-byte aligned");
+  if (g.epilogue == HM_EPI_RESID_F32 && (!g.resid || g.ldr < g.N || g.ldr % 4 != 0))
+    return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: residual epilogue needs resid and ldr >= N, ldr % 4 == 0");
+  if (g.epilogue == HM_EPI_GELU_MX8 && !g.out_scales) return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: HM_EPI_GELU_MX8 needs out_scales");
+  KArgs k{};
+  k.X = g.X8; k.W = g.W8; k.C = g.C; k.bias = g.bias; k.resid = g.resid;
+  k.M = g.M; k.N = g.N; k.K = g.K; k.ldx = g.ldx; k.ldw = g.ldw; k.ldc = g.ldc; k.ldr = g.ldr; k.resid_mod = 0;
+  k.group_m = g_group_m; k.ksplit = 1;
+  k.xs = (const unsigned char*)g.x_scales; k.wscale = g.w_scale; k.out_scales = (unsigned char*)g.out_scales;
+  HmProfScope prof(HM_K_GEMM, 16 + g.epilogue, g.M, g.N, g.K, stream);
+  switch (g.epilogue) {
+    case HM_EPI_STORE:
+      if (g.out_dtype != HM_DTYPE_BF16) return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: HM_EPI_STORE writes bf16 (out_dtype HM_DTYPE_BF16)");
+      return launch_fp8<HM_EPI_STORE>(k, stream);
+    case HM_EPI_RESID_F32: return launch_fp8<HM_EPI_RESID_F32>(k, stream);
+    case HM_EPI_GELU_MX8: return launch_fp8<HM_EPI_GELU_MX8>(k, stream);
+    default: return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: epilogue must be STORE, RESID_F32 or GELU_MX8");
+  }
 }
 
 extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {

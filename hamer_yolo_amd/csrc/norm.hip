@@ -88,6 +88,53 @@ __global__ __launch_bounds__(256, 8) void layernorm_kernel(const float* __restri
   }
 }
 
+// LayerNorm with MXFP8 output for hm_gemm_fp8: the 8 lanes that hold 32 consecutive columns agree on the block's E8M0
+// scale (DPP max), every lane packs its 4 values into one dword of e4m3 bytes.  Scales go to [D/32][M].
+template <int MAXJ>
+__global__ __launch_bounds__(256, 8) void layernorm_mx8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int* __restrict__ out8,
+                                                            unsigned char* __restrict__ scales, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  f32x4_t v[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int i = lane * 4 + j * 256;
+    v[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (i < D) v[j] = *(const f32x4_t*)(xr + i);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int i = lane * 4 + j * 256;
+    if (i < D) {
+      const f32x4_t d = v[j] - mean;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int i = lane * 4 + j * 256;
+    const bool ok = i < D;                             // whole 8-lane groups are in or out (D % 32 == 0)
+    f32x4_t y = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (ok) y = (v[j] - mean) * rstd * *(const f32x4_t*)(gamma + i) + *(const f32x4_t*)(beta + i);
+    const float amax = row8_max(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+    const unsigned sb = mx8_scale_byte(amax);
+    const float inv = mx8_inv_scale(sb);
+    if (ok) {
+      out8[((size_t)row * D + i) >> 2] = mx8_pack4(y[0] * inv, y[1] * inv, y[2] * inv, y[3] * inv);
+      if ((lane & 7) == 0) scales[(size_t)(i >> 5) * M + row] = (unsigned char)sb;
+    }
+  }
+}
+
 template <class OutT>
 void launch_ln(const float* x, const float* g, const float* b, OutT* out, int M, int D, float eps, hipStream_t s) {
   dim3 grid((M + 3) / 4), block(256);
@@ -143,6 +190,21 @@ extern "C" int hm_layernorm_accum(float* x, const float* partials, int n_partial
   else if (out_dtype == HM_OUT_F32) launch_ln_acc<float>(x, partials, n_partials, bias, gamma, beta, (float*)out, M, D, eps, s);
   else return hm_set_error(HM_ERR_ARG, "hm_layernorm_accum: bad out_dtype");
   return hm_check_launch("hm_layernorm_accum");
+}
+
+extern "C" int hm_layernorm_mx8(const float* x, const float* gamma, const float* beta, void* out8, void* out_scales, int M,
+                                int D, float eps, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!x || !gamma || !beta || !out8 || !out_scales) return hm_set_error(HM_ERR_ARG, "hm_layernorm_mx8: null pointer");
+  if (M <= 0 || D <= 0 || D % 32 != 0 || D > 256 * MAXJ_LIMIT)
+    return hm_set_error(HM_ERR_ARG, "hm_layernorm_mx8: need 0 < D <= 2048, D % 32 == 0, M > 0");
+  HmProfScope prof(HM_K_LAYERNORM, 3, M, D, 0, s);
+  dim3 grid((M + 3) / 4), block(256);
+  const int mj = (D + 255) / 256;
+  if (mj <= 2) hipLaunchKernelGGL((layernorm_mx8_kernel<2>), grid, block, 0, s, x, gamma, beta, (int*)out8, (unsigned char*)out_scales, M, D, eps);
+  else if (mj <= 5) hipLaunchKernelGGL((layernorm_mx8_kernel<5>), grid, block, 0, s, x, gamma, beta, (int*)out8, (unsigned char*)out_scales, M, D, eps);
+  else hipLaunchKernelGGL((layernorm_mx8_kernel<8>), grid, block, 0, s, x, gamma, beta, (int*)out8, (unsigned char*)out_scales, M, D, eps);
+  return hm_check_launch("hm_layernorm_mx8");
 }
 
 extern "C" int hm_broadcast_rows(const float* vec, float* out, int B, int D, void* stream_) {

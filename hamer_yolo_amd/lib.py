@@ -14,14 +14,14 @@ LIB_PATH = os.path.join(HERE, "libhamer_hip.so")
 
 HM_DTYPE_BF16, HM_DTYPE_F16, HM_OUT_F32 = 0, 1, 2
 HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 3, 4
-HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU = 5, 6, 7
+HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU, HM_EPI_GELU_MX8 = 5, 6, 7, 8
 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
     "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
-    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_hamer_forward_split", "hm_ln_finalize", "hm_layernorm_accum",
+    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_hamer_forward_split", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -39,6 +39,12 @@ class GemmArgs(C.Structure):
                 ("ldx", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
                 ("resid_mod", C.c_int), ("epilogue", C.c_int), ("dtype", C.c_int),
                 ("ln_gamma", vp), ("ln_xg", vp), ("ln_stats", vp), ("ln_colsum", vp), ("k_split", C.c_int)]
+
+
+class GemmFp8Args(C.Structure):
+    _fields_ = [("X8", vp), ("x_scales", vp), ("W8", vp), ("w_scale", vp), ("C", vp), ("bias", vp), ("resid", vp),
+                ("out_scales", vp), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ldx", C.c_int), ("ldw", C.c_int),
+                ("ldc", C.c_int), ("ldr", C.c_int), ("epilogue", C.c_int), ("out_dtype", C.c_int)]
 
 
 class ManoModel(C.Structure):
@@ -130,6 +136,8 @@ def load() -> C.CDLL:
     lib.hm_hamer_forward.argtypes = [C.POINTER(HamerWeights), vp, i, C.POINTER(HamerOutputs), vp, C.c_size_t, vp]
     lib.hm_hamer_forward_split.argtypes = [C.POINTER(HamerWeights), vp, i, C.POINTER(HamerOutputs), vp, C.c_size_t, vp, vp, vp, vp]
     lib.hm_ln_finalize.argtypes = [vp, vp, i, i, C.c_float, vp]
+    lib.hm_gemm_fp8.argtypes = [C.POINTER(GemmFp8Args), vp]
+    lib.hm_layernorm_mx8.argtypes = [vp, vp, vp, vp, vp, i, i, C.c_float, vp]
     lib.hm_layernorm_accum.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, C.c_float, vp]
     lib.hm_conv2d_nhwc.argtypes = [C.POINTER(ConvArgs), vp]
     lib.hm_maxpool_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, i, vp]

@@ -76,6 +76,42 @@ def layernorm_accum(x: torch.Tensor, partials: torch.Tensor, bias: Optional[torc
     return out
 
 
+def layernorm_mx8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    """LayerNorm -> MXFP8: (out8 (M,D) uint8 of e4m3 bytes, scales (D/32, M) uint8 E8M0)."""
+    _dev(x, gamma, beta)
+    M, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out8 = torch.empty(M, D, device=x.device, dtype=torch.uint8)
+    scales = torch.empty(D // 32, M, device=x.device, dtype=torch.uint8)
+    L.check(L.load().hm_layernorm_mx8(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(out8), L.ptr(scales), M, D, eps,
+                                      L.current_stream()), "hm_layernorm_mx8")
+    return out8, scales
+
+
+def gemm_fp8(x8: torch.Tensor, x_scales: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, epilogue: int = L.HM_EPI_STORE, resid: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None):
+    """epilogue(dequant(x8, x_scales) @ (dequant(w8) * w_scale).T + bias).  x8 (M,K) / w8 (N,K) uint8 e4m3 bytes, x_scales
+    (K/32, M) uint8 E8M0, w_scale (N,) f32.  HM_EPI_STORE -> bf16; HM_EPI_RESID_F32 -> f32 (+resid); HM_EPI_GELU_MX8 ->
+    (uint8 (M,N), scales (N/32, M))."""
+    _dev(x8, x_scales, w8, w_scale, bias, resid, out)
+    M, K = x8.shape
+    N = w8.shape[0]
+    assert x8.dtype == torch.uint8 and w8.dtype == torch.uint8 and w8.shape[1] == K and x8.stride(1) == 1 and w8.stride(1) == 1
+    assert x_scales.shape == (K // 32, M) and x_scales.is_contiguous() and w_scale.shape == (N,)
+    out_scales = None
+    if out is None:
+        dt = {L.HM_EPI_STORE: torch.bfloat16, L.HM_EPI_RESID_F32: torch.float32, L.HM_EPI_GELU_MX8: torch.uint8}[epilogue]
+        out = torch.empty(M, N, device=x8.device, dtype=dt)
+    if epilogue == L.HM_EPI_GELU_MX8:
+        out_scales = torch.empty(N // 32, M, device=x8.device, dtype=torch.uint8)
+    a = L.GemmFp8Args(L.ptr(x8), L.ptr(x_scales), L.ptr(w8), L.ptr(w_scale), L.ptr(out), L.ptr(bias), L.ptr(resid),
+                      L.ptr(out_scales), M, N, K, x8.stride(0), w8.stride(0), out.stride(0),
+                      resid.stride(0) if resid is not None else 0, epilogue, L.HM_DTYPE_BF16)
+    L.check(L.load().hm_gemm_fp8(C.byref(a), L.current_stream()), "hm_gemm_fp8")
+    return (out, out_scales) if epilogue == L.HM_EPI_GELU_MX8 else out
+
+
 def ln_finalize(partials: torch.Tensor, eps: float) -> torch.Tensor:
     """(D/64, M, 2) partial (sum, sum of squares) -> (M, 2) (mean, rstd)."""
     _dev(partials)

@@ -40,7 +40,8 @@ enum {
    * LN(x).W^T + b = rstd * ((x*gamma).W^T - mean * colsum) + (b + W.beta), colsum[n] = sum_k W[n][k]*gamma[k] */
   HM_EPI_RESID_LN = 5,  /* RESID_F32, plus ln_xg = C*ln_gamma (16-bit) and ln_stats     */
   HM_EPI_LN_STORE = 6,  /* C(16-bit) = rstd*(acc - mean*ln_colsum) + bias               */
-  HM_EPI_LN_GELU = 7    /* C(16-bit) = gelu_erf(rstd*(acc - mean*ln_colsum) + bias)     */
+  HM_EPI_LN_GELU = 7,   /* C(16-bit) = gelu_erf(rstd*(acc - mean*ln_colsum) + bias)     */
+  HM_EPI_GELU_MX8 = 8   /* hm_gemm_fp8 only: C = MXFP8(gelu_erf(acc + bias)): e4m3 bytes + E8M0 scale per 32 columns */
 };
 
 typedef struct hm_gemm_args {
@@ -78,6 +79,26 @@ int hm_ln_finalize(const float* partials, float* row_stats, int M, int D, float 
 int hm_gemm_set_variant(int variant);
 /* Tuning hook: M-tiles per group in the XCD-aware tile walk (default 8). */
 int hm_gemm_set_group_m(int group_m);
+
+/* The fp8 flavour of hm_gemm for BASELINE configs[4] ("fp8 ViT-H weights on CDNA4 fp8 MFMA"): C = epilogue(X . W^T) on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 MFMA rate, half the operand bytes).
+ *   X : MXFP8 -- e4m3 (OCP) bytes [M][ldx] plus one E8M0 scale per row and 32 K-elements, stored [K/32][M]
+ *       (written by hm_layernorm_mx8 and by the HM_EPI_GELU_MX8 epilogue);
+ *   W : e4m3 bytes [N][ldw] with one f32 scale per output channel (w_scale[n] = max|W[n]| / 448);
+ *   epilogues HM_EPI_STORE (16-bit C, out_dtype), HM_EPI_RESID_F32, HM_EPI_GELU_MX8 (C bytes [M][ldc], out_scales [N/32][M]).
+ * M % 16 == 0, N % 64 == 0, K % 128 == 0. */
+typedef struct hm_gemm_fp8_args {
+  const void* X8; const void* x_scales;
+  const void* W8; const float* w_scale;
+  void* C; const float* bias; const float* resid; void* out_scales;
+  int M, N, K, ldx, ldw, ldc, ldr;
+  int epilogue;
+  int out_dtype;      /* HM_EPI_STORE: HM_DTYPE_BF16 or HM_DTYPE_F16 */
+} hm_gemm_fp8_args;
+int hm_gemm_fp8(const hm_gemm_fp8_args* args, void* stream);
+/* nn.LayerNorm with MXFP8 output (the X operand of hm_gemm_fp8): out8 [M][D] e4m3, out_scales [D/32][M] E8M0.  D % 32 == 0. */
+int hm_layernorm_mx8(const float* x, const float* gamma, const float* beta, void* out8, void* out_scales, int M, int D,
+                     float eps, void* stream);
 
 /* nn.LayerNorm over the last dim (vit.py:136,:144,:252 eps 1e-6; t_cond_mlp.py:51-52 eps 1e-5).
  * x [M][D] f32 -> out [M][D]; out_dtype: HM_DTYPE_BF16 / HM_DTYPE_F16 / HM_OUT_F32. */

@@ -1,0 +1,103 @@
+"""GPU parity of the fp8 path (BASELINE configs[4]) against the fp8-quantised oracle (oracle/fp8_ref.py).
+
+hm_gemm_fp8 is exact up to fp32 accumulation order once both sides see the same e4m3 bytes and scales, so the
+tolerances below are those of the 16-bit GEMM tests; quantisers (LayerNorm -> MXFP8, GELU -> MXFP8) must reproduce
+the oracle's bytes except where a last-bit fp32 difference crosses an e4m3 rounding boundary.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hamer_yolo_amd import lib as L
+from hamer_yolo_amd import ops, synth
+from oracle import fp8_ref as Q
+
+DEV = "cuda"
+
+
+def _u(name, shape, hw=1.0, seed=0, center=0.0):
+    return synth.uniform(name, shape, hw, center, seed=seed)
+
+
+def _operands(M, N, K, seed):
+    x = _u("fx", (M, K), 2.0, seed=seed) * (1.0 + 4.0 * _u("fxr", (M, 1), 0.5, seed=seed + 1, center=0.5))   # rows of different size
+    w = _u("fw", (N, K), 0.05, seed=seed + 2) * (0.2 + _u("fwr", (N, 1), 0.5, seed=seed + 3, center=0.5))
+    x8, xs = Q.mx8_quantize(x)
+    w8, ws = Q.quantize_weight(w)
+    ref = Q.mx8_dequantize(x8, xs).double() @ Q.dequantize_weight(w8, ws).double().t()
+    return x8, xs, w8, ws, ref
+
+
+def test_gemm_fp8_exact_integers():
+    """Small-integer e4m3 values and power-of-two scales: every product and sum is exact in fp32 -> bit-exact result,
+    which pins the operand and scale lane maps of v_mfma_scale_f32_16x16x128_f8f6f4 through the whole kernel."""
+    M, N, K = 272, 320, 384
+    xi = (torch.arange(M * K).reshape(M, K) * 7 % 9 - 4).float()                       # -4 .. 4
+    wi = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 7 - 3).float()
+    x8 = xi.to(torch.float8_e4m3fn).view(torch.uint8)
+    w8 = wi.to(torch.float8_e4m3fn).view(torch.uint8)
+    xs = (127 + (torch.arange(K // 32)[:, None] * 3 + torch.arange(M)[None, :]) % 4 - 1).to(torch.uint8)     # 2^-1 .. 2^2
+    ws = torch.ldexp(torch.ones(N), (torch.arange(N) % 3 - 1).to(torch.int32))
+    ref = (Q.mx8_dequantize(x8, xs).double() @ (wi.double() * ws.double()[:, None]).t())
+    out = ops.gemm_fp8(x8.to(DEV), xs.to(DEV), w8.to(DEV), ws.to(DEV), None, L.HM_EPI_RESID_F32,
+                       resid=torch.zeros(M, N, device=DEV))
+    assert torch.equal(out.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 3840, 1280), (768, 1280, 5120), (1040, 320, 256), (16, 64, 128)])
+def test_gemm_fp8_epilogues(M, N, K):
+    x8, xs, w8, ws, ref = _operands(M, N, K, seed=M + N)
+    bias, resid = _u("fb", (N,), 0.5, seed=5), _u("fr", (M, N), 1.0, seed=6)
+    a = (x8.to(DEV), xs.to(DEV), w8.to(DEV), ws.to(DEV), bias.to(DEV))
+    scale = ref.abs().max().item()
+    o = ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=resid.to(DEV)).cpu().double()
+    np.testing.assert_allclose(o.numpy(), (ref + bias.double() + resid.double()).numpy(), atol=2e-6 * scale * math.sqrt(K), rtol=1e-5)
+    o = ops.gemm_fp8(*a, L.HM_EPI_STORE).cpu().float()
+    np.testing.assert_allclose(o.numpy(), (ref + bias.double()).float().numpy(), atol=1e-5 * scale * math.sqrt(K), rtol=2 ** -7)
+    # GELU -> MXFP8: bytes and scales against the oracle quantiser applied to the fp64 result
+    o8, os_ = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
+    g = F.gelu((ref + bias.double()).float())
+    r8, rs = Q.mx8_quantize(g)
+    same_scale = (os_.cpu() == rs).float().mean().item()
+    assert same_scale > 0.995, same_scale
+    d_k, d_r = Q.mx8_dequantize(o8.cpu(), os_.cpu()), Q.mx8_dequantize(r8, rs)
+    err = (d_k - d_r).abs()
+    blockmax = d_r.abs().reshape(M, N // 32, 32).amax(-1, keepdim=True).expand(M, N // 32, 32).reshape(M, N)
+    assert (err <= blockmax * 2.0 ** -3 + 1e-6).all()              # never more than one e4m3 step of the block's range
+    assert (err == 0).float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("D", [1280, 320])
+def test_layernorm_mx8(D):
+    M = 520
+    x = _u("lx", (M, D), 2.0, seed=D) + _u("lxr", (M, 1), 3.0, seed=D + 1)
+    gamma, beta = _u("lg", (D,), 0.3, seed=3, center=1.0), _u("lb", (D,), 0.2, seed=4)
+    o8, os_ = ops.layernorm_mx8(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6)
+    y = F.layer_norm(x, (D,), gamma, beta, 1e-6)
+    r8, rs = Q.mx8_quantize(y)
+    assert (os_.cpu() == rs).float().mean().item() > 0.995
+    d_k, d_r = Q.mx8_dequantize(o8.cpu(), os_.cpu()), Q.mx8_dequantize(r8, rs)
+    assert not torch.isnan(d_k).any()
+    err = (d_k - d_r).abs()
+    blockmax = d_r.abs().reshape(M, D // 32, 32).amax(-1, keepdim=True).expand(M, D // 32, 32).reshape(M, D)
+    assert (err <= blockmax * 2.0 ** -3 + 1e-6).all()
+    assert (err == 0).float().mean().item() > 0.99
+    # and the quantised rows still are the LayerNorm to e4m3 precision
+    assert ((d_k - y).abs() <= blockmax * 2.0 ** -4 + 1e-6).float().mean().item() > 0.999
+
+
+def test_gemm_fp8_rejects_bad_arguments():
+    x8 = torch.zeros(16, 128, device=DEV, dtype=torch.uint8)
+    xs = torch.zeros(4, 16, device=DEV, dtype=torch.uint8)
+    w8 = torch.zeros(64, 128, device=DEV, dtype=torch.uint8)
+    ws = torch.ones(64, device=DEV)
+    ops.gemm_fp8(x8, xs, w8, ws)                                   # smallest legal problem
+    with pytest.raises(L.HipLibraryError):
+        ops.gemm_fp8(x8[:, :64].contiguous(), xs[:2].contiguous(), w8[:, :64].contiguous(), ws)      # K % 128 != 0
+    with pytest.raises(L.HipLibraryError):
+        ops.gemm_fp8(x8, xs, w8[:48].contiguous(), ws[:48].contiguous())                             # N % 64 != 0
