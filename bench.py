@@ -28,7 +28,9 @@ from hamer_yolo_amd import shard, synth  # noqa: E402
 from hamer_yolo_amd.engine import HamerEngine  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-EPI_NAMES = {0: "store", 1: "gelu", 2: "resid_f32", 3: "f32", 4: "silu", 5: "resid_ln", 6: "ln_store", 7: "ln_gelu"}
+EPI_NAMES = {0: "store", 1: "gelu", 2: "resid_f32", 3: "f32", 4: "silu", 5: "resid_ln", 6: "ln_store", 7: "ln_gelu",
+             16: "fp8_store", 18: "fp8_resid_f32", 24: "fp8_gelu_mx8"}
+PEAK_FP8_TFLOPS = 5000.0       # dense e4m3 on the block-scaled 16x16x128 MFMA (MI355X_MICROARCH.md)
 
 
 def flops_per_hand(cfg: synth.HamerConfig) -> dict:
@@ -132,7 +134,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE config: 64)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"],
+                    help="fp8: BASELINE configs[4] (qkv/fc1/fc2 on the fp8 MFMA, MXFP8 activations); use with --batch 256")
     ap.add_argument("--workload", default="crops", choices=["crops", "e2e"],
                     help="crops: BASELINE configs[1] (default, the contract line); e2e: configs[2], 1080p frames through "
                          "YOLOv7 + crop + HaMeR with 4 fixed boxes per frame (not a contract line, for DESIGN.md)")
@@ -151,7 +154,7 @@ def main():
     dev = torch.device("cuda", local)
     dist = torch.distributed
     cfg = synth.HamerConfig()
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     B = args.batch
 
     if args.workload == "e2e":
@@ -166,7 +169,7 @@ def main():
     else:
         sd = sd0
     mano_cpu = synth.mano_params(seed=0)
-    eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype)
+    eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype, fp8=(args.dtype == "fp8"))
 
     # this rank's shard of the global crop set (seeds rank*B .. rank*B+B-1), resident in HBM
     img = synth.normalize_crops(synth.crops_u8(B, seed0=rank * B)).to(dev)
@@ -209,8 +212,11 @@ def main():
             "value": round(hands / elapsed, 2), "unit": "hands/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=64 synthetic 256x256 crops per GPU, HaMeR ViT-H/16 "
-                                   "+ 6-layer decoder + MANO, 16-bit MFMA, crops resident in HBM",
+            "config": {"workload": ("BASELINE configs[4]: batch=%d synthetic 256x256 crops per GPU, HaMeR ViT-H/16 with qkv/fc1/fc2 "
+                                    "in e4m3 on the block-scaled fp8 MFMA (MXFP8 activations), proj/attention bf16, fp32 residual, "
+                                    "decoder and MANO, crops resident in HBM" % B) if args.dtype == "fp8" else
+                                   "BASELINE configs[1]: batch=%d synthetic 256x256 crops per GPU, HaMeR ViT-H/16 "
+                                   "+ 6-layer decoder + MANO, 16-bit MFMA, crops resident in HBM" % B,
                        "batch_per_gpu": B, "global_batch": world * B, "weights": "seeded random-init (bf16-representable)",
                        "parallelism": f"crop-shard x{world}", "mfma_gflop_per_hand": round(fl["total_mfma"] / 1e9, 2)},
             "model_mfma_frac": round(hands / elapsed * fl["total_mfma"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
@@ -240,9 +246,14 @@ def main():
             t = json.load(open(traffic_src))
             w = {"patch": 1, "qkv": cfg.vit.depth, "proj": cfg.vit.depth, "fc1": cfg.vit.depth, "fc2": cfg.vit.depth, "kv": 1}
             traffic = round(sum(t[k]["hbm_bytes"] * n for k, n in w.items()) / sum(w.values()))
+        kernel_name, peak = "gemm_tn_kernel (all epilogues)", PEAK_BF16_TFLOPS
+        if args.dtype == "fp8":      # dominant kernel = gemm_fp8_kernel: price its launches against the fp8 peak
+            f8 = [(M_, N_, K_, ms_) for (kd, e_, M_, N_, K_, ms_) in prof.records if kd == "gemm" and e_ >= 16]
+            achieved = sum(2.0 * a * b * c for a, b, c, _ in f8) / (sum(t for *_, t in f8) * 1e-3) / 1e12
+            kernel_name, peak, traffic = "gemm_fp8_kernel (store / gelu_mx8 / resid_f32)", PEAK_FP8_TFLOPS, None
         res["roofline"] = {
-            "kernel": "gemm_tn_kernel (all epilogues)", "bound": "mfma", "achieved": round(achieved, 2),
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "kernel": kernel_name, "bound": "mfma", "achieved": round(achieved, 2),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_note": "bytes per launch beyond L2 (FETCH_SIZE*2 + WRITE_SIZE, PMC pass committed under profiles/; Infinity-Cache hits included), "
                             "algorithmic operand+result bytes per launch: %d" % round(sum(
                                 (2 * (M_ * K_ + N_ * K_) + M_ * N_ * {2: 8, 5: 10}.get(e_, 2)) for (_, e_, M_, N_, K_, _) in

@@ -11,7 +11,7 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, partials, total;
+  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, hs, mlps, partials, total;
   int ksplit_proj, ksplit_fc2;
 };
 
@@ -48,6 +48,8 @@ Layout make_layout(const hm_hamer_weights& w, int B) {
   L.head = o; o += align256((size_t)B * 112 * 4);
   L.stats = o; o += align256(M * ((D + 63) / 64) * 8);      // deferred-LN partials [D/64][M][2]
   L.rowstats = o; o += align256(M * 8);                      // (mean, rstd) per row
+  L.hs = o; o += align256(((D + 31) / 32) * M);               // fp8 path: E8M0 scales of the MXFP8 LayerNorm output [D/32][M]
+  L.mlps = o; o += align256((((size_t)w.mlp_dim + 31) / 32) * M);   // ... and of the GELU output [mlp/32][M]
   // split-K of the two N = D GEMMs of a block when their 128x128 tiles would leave most CUs idle (a few hands)
   L.ksplit_proj = pick_split_k((int)M, (int)D, (int)D);
   L.ksplit_fc2 = pick_split_k((int)M, (int)D, w.mlp_dim);
@@ -123,7 +125,21 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
     HM_TRY(gemm(X, K, W, K, D, x, D, bias, HM_EPI_RESID_F32, x, D, 0));
     return hm_layernorm(x, ln_g, ln_b, ln_out, dt, M, D, w->vit_eps, stream);
   };
-  bool fold = D % 64 == 0 && w->depth > 0;
+  // fp8 path (BASELINE configs[4]): qkv / fc1 / fc2 on hm_gemm_fp8 when every block carries e4m3 weights
+  bool fp8 = dt == HM_DTYPE_BF16 && D % 128 == 0 && w->mlp_dim % 128 == 0 && w->depth > 0;
+  for (int i = 0; i < w->depth && fp8; ++i) {
+    const hm_vit_block& b = w->blocks[i];
+    fp8 = b.qkv_w8 && b.qkv_ws && b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws;
+  }
+  void *hs = ws + L.hs, *mlps = ws + L.mlps;
+  auto gemm8 = [&](const void* X8, const void* xsc, int K, const void* W8, const float* wsc, int N, void* C, int ldc,
+                   const float* bias, int epi, const float* resid, void* out_scales) {
+    hm_gemm_fp8_args g{};
+    g.X8 = X8; g.x_scales = xsc; g.W8 = W8; g.w_scale = wsc; g.C = C; g.bias = bias; g.resid = resid; g.out_scales = out_scales;
+    g.M = M; g.N = N; g.K = K; g.ldx = K; g.ldw = K; g.ldc = ldc; g.ldr = ldc; g.epilogue = epi; g.out_dtype = HM_DTYPE_BF16;
+    return hm_gemm_fp8(&g, stream);
+  };
+  bool fold = !fp8 && D % 64 == 0 && w->depth > 0;
   for (int i = 0; i < w->depth && fold; ++i) {
     const hm_vit_block& b = w->blocks[i];
     fold = b.qkv_colsum && b.qkv_bias_ln && b.fc1_colsum && b.fc1_bias_ln;
@@ -137,7 +153,16 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
   else HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
   for (int i = 0; i < w->depth; ++i) {
     const hm_vit_block& b = w->blocks[i];
-    if (fold) {
+    if (fp8) {
+      // h / mlp hold e4m3 bytes here (half of their 16-bit size), hs / mlps the block scales
+      HM_TRY(hm_layernorm_mx8(x, b.ln1_g, b.ln1_b, h, hs, M, D, w->vit_eps, stream));
+      HM_TRY(gemm8(h, hs, D, b.qkv_w8, b.qkv_ws, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, nullptr));
+      HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
+      HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, D, 0));
+      HM_TRY(hm_layernorm_mx8(x, b.ln2_g, b.ln2_b, h, hs, M, D, w->vit_eps, stream));
+      HM_TRY(gemm8(h, hs, D, b.fc1_w8, b.fc1_ws, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU_MX8, nullptr, mlps));
+      HM_TRY(gemm8(mlp, mlps, w->mlp_dim, b.fc2_w8, b.fc2_ws, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, nullptr));
+    } else if (fold) {
       HM_TRY(gemm(h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_bias_ln, HM_EPI_LN_STORE, nullptr, 0, 0, b.qkv_colsum));
       HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
       HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_LN, x, D, 0, b.ln2_g));
@@ -158,7 +183,7 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
     if (i == 0 && after_first_block && hipEventRecord(after_first_block, (hipStream_t)stream) != hipSuccess)
       return hm_set_error(HM_ERR_HIP, "hm_hamer_forward_split: hipEventRecord failed");
   }
-  if (fold) HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
+  if (fold || fp8) HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
 
   // ---- decoder head (mano_head.py:61-95, pose_transformer.py:191-201)
   const int dim = w->dec_dim, inner = w->dec_heads * w->dec_dim_head, ldkv = w->dec_depth * 2 * inner;

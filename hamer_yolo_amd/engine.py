@@ -22,7 +22,8 @@ from .synth import HamerConfig
 
 class HamerEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], mano: Dict[str, torch.Tensor],
-                 cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.bfloat16, fold_ln: Optional[bool] = None):
+                 cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.bfloat16, fold_ln: Optional[bool] = None,
+                 fp8: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise L.HipLibraryError("HamerEngine needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = L.load()
@@ -58,6 +59,21 @@ class HamerEngine:
             g64, b64 = gamma.detach().to(self.device, torch.float64), beta.detach().to(self.device, torch.float64)
             return f32(Wd @ g64), f32(bias.detach().to(self.device, torch.float64) + Wd @ b64)
 
+        # fp8 path (BASELINE configs[4]): qkv / fc1 / fc2 weights in e4m3 with per-channel scales, MXFP8 activations
+        if fp8 is None:
+            fp8 = os.environ.get("HAMER_FP8", "0") == "1"
+        self.fp8 = bool(fp8)
+        if self.fp8:
+            if dtype != torch.bfloat16 or v.embed_dim % 128 != 0:
+                raise L.HipLibraryError("the fp8 path needs dtype=bfloat16 and embed_dim % 128 == 0")
+            self.fold_ln = False
+            from .quant import quantize_weight_e4m3
+
+        def w8(t):
+            q, sc = quantize_weight_e4m3(t.detach().to(self.device))
+            self._keep += [q, sc]
+            return L.ptr(q), L.ptr(sc)
+
         D = v.embed_dim
         self.blocks = (L.VitBlock * v.depth)()
         for i in range(v.depth):
@@ -69,6 +85,10 @@ class HamerEngine:
             b.proj_w, b.proj_b = L.ptr(w16(sd[p + "attn.proj.weight"])), L.ptr(f32(sd[p + "attn.proj.bias"]))
             b.fc1_w, b.fc1_b = L.ptr(w16(sd[p + "mlp.fc1.weight"])), L.ptr(f32(sd[p + "mlp.fc1.bias"]))
             b.fc2_w, b.fc2_b = L.ptr(w16(sd[p + "mlp.fc2.weight"])), L.ptr(f32(sd[p + "mlp.fc2.bias"]))
+            if self.fp8:
+                b.qkv_w8, b.qkv_ws = w8(sd[p + "attn.qkv.weight"])
+                b.fc1_w8, b.fc1_ws = w8(sd[p + "mlp.fc1.weight"])
+                b.fc2_w8, b.fc2_ws = w8(sd[p + "mlp.fc2.weight"])
             if self.fold_ln:
                 cs, bl = ln_fold(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], sd[p + "norm1.weight"], sd[p + "norm1.bias"])
                 b.qkv_colsum, b.qkv_bias_ln = L.ptr(cs), L.ptr(bl)

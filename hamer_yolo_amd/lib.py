@@ -60,7 +60,8 @@ class CropBox(C.Structure):
 class VitBlock(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "proj_w", "fc1_w", "fc2_w",
                                   "qkv_b", "proj_b", "fc1_b", "fc2_b",
-                                  "qkv_colsum", "qkv_bias_ln", "fc1_colsum", "fc1_bias_ln")]
+                                  "qkv_colsum", "qkv_bias_ln", "fc1_colsum", "fc1_bias_ln",
+                                  "qkv_w8", "fc1_w8", "fc2_w8", "qkv_ws", "fc1_ws", "fc2_ws")]
 
 
 class DecLayer(C.Structure):

@@ -184,6 +184,11 @@ typedef struct hm_vit_block {
    * *_colsum[n] = sum_k W[n][k]*ln_g[k] over the 16-bit weights, *_bias_ln = b + W.ln_b.  When present
    * hm_hamer_forward runs no LayerNorm kernel inside the blocks. */
   const float *qkv_colsum, *qkv_bias_ln, *fc1_colsum, *fc1_bias_ln;
+  /* optional (all six, in every block, or none; dtype must be HM_DTYPE_BF16): the fp8 path of BASELINE configs[4].
+   * e4m3 bytes [N][K] and one f32 scale per output channel for qkv / fc1 / fc2; hm_hamer_forward then runs those three
+   * GEMMs through hm_gemm_fp8 with MXFP8 activations (hm_layernorm_mx8, HM_EPI_GELU_MX8); proj stays 16-bit. */
+  const void *qkv_w8, *fc1_w8, *fc2_w8;
+  const float *qkv_ws, *fc1_ws, *fc2_ws;
 } hm_vit_block;
 
 typedef struct hm_dec_layer {

@@ -29,12 +29,20 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 
 
-def _q(x: Tensor, emu: bool) -> Tensor:
+def _q(x: Tensor, emu) -> Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if emu else x
 
 
-def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], emu: bool) -> Tensor:
+def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], emu) -> Tensor:
     return F.linear(_q(x, emu), _q(w, emu), b)
+
+
+def _linear_fp8(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """The fp8 GEMMs of emu == "fp8" (BASELINE configs[4]; qkv, fc1, fc2): X in MXFP8 blocks of 32 along K, W in e4m3
+    with one scale per output channel (oracle/fp8_ref.py), fp32 accumulation."""
+    from . import fp8_ref as Q
+    w8, ws = Q.quantize_weight(w)
+    return F.linear(Q.fake_quant_mx8(x), Q.dequantize_weight(w8, ws), b)
 
 
 # ----------------------------------------------------------------------------- ViT backbone
@@ -49,7 +57,10 @@ def patch_embed(sd, x: Tensor, vit, emu=False, prefix="backbone.") -> Tensor:
 def vit_attention(sd, h: Tensor, p: str, vit, emu=False) -> Tensor:
     """Attention.forward, vit.py:110-126."""
     B, N, C = h.shape
-    qkv = _q(_linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], emu), emu)
+    if emu == "fp8":
+        qkv = _q(_linear_fp8(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]), True)
+    else:
+        qkv = _q(_linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], emu), emu)
     qkv = qkv.reshape(B, N, 3, vit.heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     scale = vit.head_dim ** -0.5
@@ -69,6 +80,9 @@ def vit_attention(sd, h: Tensor, p: str, vit, emu=False) -> Tensor:
 
 def vit_mlp(sd, h: Tensor, p: str, emu=False) -> Tensor:
     """Mlp.forward, vit.py:82-87 (exact-erf GELU)."""
+    if emu == "fp8":
+        y = F.gelu(_linear_fp8(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+        return _linear_fp8(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
     y = F.gelu(_linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], emu))
     return _linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], emu)
 
