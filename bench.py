@@ -128,6 +128,19 @@ def run_e2e(args, dev, dtype):
                       "gflop_per_frame": 61.9 + 4 * 251.03, "ms_per_step_by_kernel": {k: round(v, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}), flush=True)
 
 
+def mfma_busy_pmc(cfg):
+    """MFMA-pipe busy fraction of the GEMM launches of one step from the committed PMC pass (rocprofv3 --pmc
+    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/pmc_shapes.py; profiles/r01_pmc_mfma_busy.json), cycle-weighted."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    w = {"patch": 1, "qkv": cfg.vit.depth, "proj": cfg.vit.depth, "fc1": cfg.vit.depth, "fc2": cfg.vit.depth, "kv": 1}
+    busy = sum(t[k]["SQ_VALU_MFMA_BUSY_CYCLES"] * n for k, n in w.items())
+    cyc = sum(t[k]["shader_cycles"] * 1024 * n for k, n in w.items())
+    return round(busy / cyc, 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +271,7 @@ def main():
                             "algorithmic operand+result bytes per launch: %d" % round(sum(
                                 (2 * (M_ * K_ + N_ * K_) + M_ * N_ * {2: 8, 5: 10}.get(e_, 2)) for (_, e_, M_, N_, K_, _) in
                                 [r for r in prof.records if r[0] == "gemm"]) / n_gemm),
+            "mfma_busy_pmc": mfma_busy_pmc(cfg) if (B == 64 and args.dtype != "fp8") else None,
             "launches_per_step": n_gemm // nprof, "avg_launch_ms": round(gemm_ms / n_gemm, 5),
             "flop_per_launch": round(gemm_fl / n_gemm),
             "per_epilogue": {k: {"launches_per_step": v[0] // nprof, "avg_ms": round(v[1] / v[0], 5),
