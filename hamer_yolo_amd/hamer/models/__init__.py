@@ -25,11 +25,11 @@ DEFAULT_CHECKPOINT = f"{CACHE_DIR_HAMER}/hamer_ckpts/checkpoints/hamer.ckpt"
 
 
 def _read_state_dict(path: str):
-    try:
-        ck = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
-        ck = torch.load(path, map_location="cpu", weights_only=False)
-    sd = ck.get("state_dict", ck)
+    """``state_dict`` of a Lightning checkpoint (or a bare state dict).  Read with the class-free unpickler: the
+    hyper-parameters stored beside the weights hold yacs / pytorch_lightning objects, which this build does not import."""
+    from ...utils.checkpoint import load_checkpoint
+    ck = load_checkpoint(path)
+    sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck
     return {k: v for k, v in sd.items() if isinstance(v, torch.Tensor)}
 
 

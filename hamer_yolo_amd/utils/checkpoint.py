@@ -1,0 +1,119 @@
+"""Reading the reference's checkpoints without the reference's classes.
+
+``yolov7_best.pt`` is a pickled ``nn.Module`` tree (``{'model': Model, 'ema': ...}``, loaded by ``attempt_load``,
+experimental.py:260-283, which needs ``models.yolo.Model`` & co. importable), and a Lightning ``hamer.ckpt`` may
+carry ``yacs`` / ``pytorch_lightning`` objects beside its ``state_dict``.  Neither package tree exists here, and
+unpickling arbitrary globals is unsafe anyway, so ``load_checkpoint`` runs ``torch.load`` with an unpickler that
+  * lets through tensors, storages, containers and numpy arrays (an allow-list), and
+  * turns every other class into an inert attribute bag (``Stub``) -- no foreign code runs.
+``module_state_dict`` then walks a stubbed module tree (``_parameters`` / ``_buffers`` / ``_modules``) and
+returns what ``module.state_dict()`` would have.
+"""
+from __future__ import annotations
+
+import pickle
+from collections import OrderedDict
+from typing import Any, Dict
+
+import torch
+
+_ALLOWED_PREFIXES = ("torch._utils", "torch.storage", "torch._tensor", "torch.serialization", "collections", "numpy")
+_ALLOWED_EXACT = {
+    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("copyreg", "_reconstructor"), ("builtins", "object"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("builtins", "slice"), ("builtins", "range"), ("builtins", "complex"), ("builtins", "bytearray"),
+    ("_codecs", "encode"), ("__builtin__", "object"), ("__builtin__", "set"),
+}
+
+
+class Stub:
+    """An unpickled foreign object: its state, no behaviour."""
+
+    def __init__(self, *args, **kwargs):
+        self._stub_args = args
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        elif isinstance(state, tuple) and len(state) == 2 and all(isinstance(s, (dict, type(None))) for s in state):
+            for s in state:
+                if s:
+                    self.__dict__.update(s)
+        else:
+            self._stub_state = state
+
+    def __call__(self, *args, **kwargs):        # e.g. a pickled partial / functools object being "called"
+        return Stub()
+
+    # dict / list / set subclasses (yacs.CfgNode, ...) are rebuilt through the container protocol
+    def __setitem__(self, key, value):
+        self.__dict__.setdefault("_stub_items", {})[key] = value
+
+    def __getitem__(self, key):
+        return self.__dict__.get("_stub_items", {})[key]
+
+    def append(self, value):
+        self.__dict__.setdefault("_stub_list", []).append(value)
+
+    def extend(self, values):
+        self.__dict__.setdefault("_stub_list", []).extend(values)
+
+    def add(self, value):
+        self.__dict__.setdefault("_stub_list", []).append(value)
+
+    def __repr__(self):
+        return f"<Stub {type(self).__module__}.{type(self).__qualname__}>"
+
+
+_stub_classes: Dict[tuple, type] = {}
+
+
+def _stub_class(module: str, name: str) -> type:
+    key = (module, name)
+    if key not in _stub_classes:
+        _stub_classes[key] = type(name, (Stub,), {"__module__": module})
+    return _stub_classes[key]
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _ALLOWED_EXACT or module.startswith(_ALLOWED_PREFIXES) or (module == "torch" and name.endswith("Storage")):
+            return super().find_class(module, name)
+        return _stub_class(module, name)
+
+
+class _PickleModule:
+    """The duck-typed ``pickle_module`` torch.load asks for."""
+    __name__ = "hamer_yolo_amd.utils.checkpoint"
+    Unpickler = _Unpickler
+    UnpicklingError = pickle.UnpicklingError
+
+    @staticmethod
+    def load(f, **kwargs):
+        return _Unpickler(f, **kwargs).load()
+
+
+def load_checkpoint(path: str) -> Any:
+    """torch.load(path) with every non-tensor class replaced by ``Stub``.  FileNotFoundError when missing."""
+    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
+
+
+def module_state_dict(mod: Any, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
+    """``nn.Module.state_dict()`` of a stubbed (or real) module tree."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    d = getattr(mod, "__dict__", {})
+    non_persistent = d.get("_non_persistent_buffers_set", set()) or set()
+    for name, p in (d.get("_parameters") or {}).items():
+        if p is not None:
+            out[prefix + name] = (p.data if hasattr(p, "data") else p).detach()
+    for name, b in (d.get("_buffers") or {}).items():
+        if b is not None and name not in non_persistent:
+            out[prefix + name] = b.detach()
+    for name, m in (d.get("_modules") or {}).items():
+        if m is not None:
+            out.update(module_state_dict(m, prefix + name + "."))
+    return out
+
+
+def is_module(obj: Any) -> bool:
+    return isinstance(getattr(obj, "__dict__", None), dict) and "_modules" in obj.__dict__ and "_parameters" in obj.__dict__

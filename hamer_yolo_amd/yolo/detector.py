@@ -18,18 +18,33 @@ from .. import synth
 from .engine import YoloEngine
 
 
+def checkpoint_state_dict(ck):
+    """The UNFUSED fp32 state dict inside what ``torch.save`` wrote: the reference's ``{'model': Model, 'ema': Model|None,
+    ...}`` with pickled modules (the EMA weights win when present, experimental.py:266), a ``{'model': state_dict}`` /
+    ``{'state_dict': ...}`` wrapper, or a bare state dict.  Keys come out as ``model.<i>...`` (the ``Model.model``
+    Sequential), as ``Model.state_dict()`` names them."""
+    from ..utils.checkpoint import is_module, module_state_dict
+    if isinstance(ck, dict) and ("model" in ck or "ema" in ck or "state_dict" in ck):
+        ck = ck.get("ema") or ck.get("model") or ck.get("state_dict")
+    sd = module_state_dict(ck) if is_module(ck) else ck
+    if not isinstance(sd, dict) or not all(isinstance(v, torch.Tensor) for v in sd.values()):
+        raise TypeError("not a YOLOv7 checkpoint: expected pickled modules or a state dict of tensors")
+    return {k: v.float() for k, v in sd.items() if v.is_floating_point()}
+
+
 def attempt_load(weights: str):
-    """experimental.py:260-283 equivalent: returns an UNFUSED state dict.  ``"synthetic:<seed>"`` draws seeded
-    random-init weights; otherwise a torch-saved dict of tensors (``{'model': state_dict}`` or a bare state dict)."""
+    """experimental.py:260-283 equivalent: returns an UNFUSED state dict (BN / RepConv / implicit folding happens in
+    YoloEngine, fuse.py).  ``"synthetic:<seed>"`` draws seeded random-init weights; a file is read with the class-free
+    unpickler (utils/checkpoint.py), so the reference's own ``yolov7_best.pt`` loads without its ``models`` package."""
     weights = str(weights)
     if weights.startswith("synthetic"):
         seed = int(weights.split(":")[1]) if ":" in weights else 0
         return synth.yolo_state_dict(seed=seed, nc=3), 3
-    ck = torch.load(weights, map_location="cpu", weights_only=True)      # FileNotFoundError when missing
-    sd = ck.get("model", ck.get("state_dict", ck)) if isinstance(ck, dict) else ck
-    if not isinstance(sd, dict):
-        raise TypeError("expected a state dict; convert pickled YOLOv7 modules with tools/convert_yolo_checkpoint.py")
+    from ..utils.checkpoint import load_checkpoint
+    sd = checkpoint_state_dict(load_checkpoint(weights))               # FileNotFoundError when missing
     det = [k for k in sd if k.endswith(".m.0.weight")]
+    if not det:
+        raise TypeError("YOLOv7 checkpoint without a detect head (no '*.m.0.weight')")
     nc = sd[det[0]].shape[0] // 3 - 5
     return sd, nc
 

@@ -192,3 +192,57 @@ def test_two_rank_broadcast_and_gather_on_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_reference_pickled_yolo_checkpoint_loads_without_its_classes(golden_dir):
+    """attempt_load (experimental.py:260-283) on a checkpoint pickled by the reference's own Model / Conv / RepConv /
+    SPPCSPC / IDetect classes (tools/gen_golden_yolo_ckpt.py): none of those packages exists here, the class-free
+    unpickler must still recover exactly Model.state_dict(), names and nc -- and run no foreign code."""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    from hamer_yolo_amd.utils.checkpoint import Stub, load_checkpoint
+    from hamer_yolo_amd.yolo.detector import checkpoint_state_dict
+    assert "yolo.yolov7.models.yolo" not in sys.modules and "models.yolo" not in sys.modules
+    g = np.load(os.path.join(golden_dir, "yolo_tiny_ckpt.npz"))
+    ck = load_checkpoint(os.path.join(golden_dir, "yolo_tiny_ckpt.pt"))
+    assert isinstance(ck["model"], Stub) and ck["epoch"] == 7 and ck["ema"] is None
+    assert list(ck["model"].names) == list(g["names"]) and ck["model"].yaml["nc"] == int(g["nc"])
+    sd = checkpoint_state_dict(ck)
+    keys = list(g["keys"])
+    assert sorted(sd) == sorted(keys)
+    for i, k in enumerate(keys):
+        assert sd[k].dtype == torch.float32
+        np.testing.assert_array_equal(sd[k].numpy(), g[f"t{i}"], err_msg=k)     # fp16 -> fp32 is exact
+    det = [k for k in sd if k.endswith(".m.0.weight")]
+    assert sd[det[0]].shape[0] // 3 - 5 == 3
+    # wrappers around plain state dicts still work
+    assert checkpoint_state_dict({"model": dict(sd)}).keys() == sd.keys()
+    with pytest.raises(TypeError):
+        checkpoint_state_dict({"model": {"a": 1}})
+
+
+def test_lightning_checkpoint_with_foreign_objects(tmp_path):
+    """A Lightning-style .ckpt whose hyper-parameters hold objects of packages that are not installed."""
+    import sys
+    import types
+    import torch
+    from hamer_yolo_amd.hamer.models import _read_state_dict
+    mod = types.ModuleType("yacs_like.config")
+    sys.modules["yacs_like"] = types.ModuleType("yacs_like")
+    sys.modules["yacs_like.config"] = mod
+
+    class CfgNode(dict):
+        pass
+    CfgNode.__module__ = "yacs_like.config"
+    CfgNode.__qualname__ = "CfgNode"
+    mod.CfgNode = CfgNode
+    sd = {"backbone.pos_embed": torch.arange(6.0).reshape(1, 2, 3), "mano_head.decpose.weight": torch.ones(2, 2)}
+    path = str(tmp_path / "hamer.ckpt")
+    try:
+        torch.save({"state_dict": sd, "hyper_parameters": {"cfg": CfgNode(MODEL=CfgNode(IMAGE_SIZE=256))}, "epoch": 1}, path)
+    finally:
+        del sys.modules["yacs_like.config"], sys.modules["yacs_like"]
+    out = _read_state_dict(path)
+    assert out.keys() == sd.keys() and all(torch.equal(out[k], sd[k]) for k in sd)
