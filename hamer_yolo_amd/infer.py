@@ -258,6 +258,125 @@ def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None,
             continue
 
 
+def _list_images(input_folder):
+    image_paths = []
+    for ext in ['*.jpg', '*.jpeg', '*.png', '*.bmp']:
+        image_paths.extend(glob.glob(os.path.join(input_folder, ext)))
+        image_paths.extend(glob.glob(os.path.join(input_folder, ext.upper())))
+    return sorted(list(set(image_paths)))
+
+
+def _detection_list(dets):
+    if isinstance(dets, list) and len(dets) > 0:
+        if isinstance(dets[0], list) and len(dets[0]) > 0 and isinstance(dets[0][0], list):
+            return dets[0]
+        return dets
+    return []
+
+
+def process_batch(input_folder, output_folder, k_real=None, hamer=None, detector=None):
+    """infer.py:908-1036: per detected hand one ``<stem>_<label>[_<n>].npz`` with the ROTATION-MATRIX form of the MANO
+    parameters: ``betas (1,10)``, ``global_orient (1,1,3,3)``, ``hand_pose (1,15,3,3)``, ``cam_t (1,3)``, ``is_right``
+    (= do_flip == 0).  A second hand with the same label gets the suffix ``_2``, ``_3`` ... (:996-998).  All hands of an
+    image go through one forward; the saved arrays are the per-hand slices the reference's one-hand calls produce."""
+    os.makedirs(output_folder, exist_ok=True)
+    if hamer is None:
+        hamer = hamer_inference(hamer_opt)
+    if detector is None:
+        from .config.yolo_config import yolo_opt
+        from .yolo.detector import Detector
+        detector = Detector(yolo_opt)
+    for img_path in _list_images(input_folder):
+        file_name = os.path.splitext(os.path.basename(img_path))[0]
+        try:
+            image = _imread_bgr(img_path)
+            if image is None:
+                continue
+            _, dets = detector.detect(image)
+            detection_list = _detection_list(dets)
+            if not detection_list:
+                continue
+            output, _ = hamer.estimate_from_rgb(image, detection_list, k_real)
+            mp = output['pred_mano_params']
+            saved_counts = {'left': 0, 'right': 0}
+            for i, bbox in enumerate(detection_list):
+                hand_label = bbox[0]
+                suffix = f"_{hand_label}"
+                if saved_counts[hand_label] > 0:
+                    suffix += f"_{saved_counts[hand_label] + 1}"
+                np.savez(os.path.join(output_folder, f"{file_name}{suffix}.npz"),
+                         betas=mp['betas'][i:i + 1].detach().cpu().numpy(),
+                         global_orient=mp['global_orient'][i:i + 1].detach().cpu().numpy(),
+                         hand_pose=mp['hand_pose'][i:i + 1].detach().cpu().numpy(),
+                         cam_t=output['pred_cam_t_full'][i:i + 1].detach().cpu().numpy(),
+                         is_right=bool(output['do_flip'][i] == 0))
+                saved_counts[hand_label] += 1
+        except Exception as e:
+            print(f"Error processing file {img_path}: {e}")
+            continue
+
+
+def get_bbox_from_npy(npy_path, target_val=3):
+    """infer.py:1040-1072: tight box [x1, y1, x2, y2] (floats) around the pixels of a label mask equal to
+    ``target_val``; None when the file or the label is missing."""
+    if not os.path.exists(npy_path):
+        print(f"[Warning] mask not found: {npy_path}")
+        return None
+    mask = np.load(npy_path)
+    rows, cols = np.where(mask == target_val)
+    if len(rows) == 0:
+        return None
+    return [float(np.min(cols)), float(np.min(rows)), float(np.max(cols)), float(np.max(rows))]
+
+
+def flip_axis_angle(rvec):
+    """infer.py:1074-1080 (the reference's mirror is disabled: it returns the vector unchanged)."""
+    return np.array([rvec[0], rvec[1], rvec[2]], dtype=rvec.dtype)
+
+
+def process_batch_manopara_with_mask(input_folder, mask_folder, output_folder, intrinsics_path=None, hamer=None):
+    """infer.py:1099-1220: no detector -- the hand box is the bounding box of label 3 in ``<mask_folder>/<stem>.npy``,
+    always treated as a right hand; intrinsics from one txt file or from ``<intrinsics_path>/<stem>.txt`` per frame.
+    Saves ``<stem>.npy`` with the same record as process_batch_manopara."""
+    os.makedirs(output_folder, exist_ok=True)
+    fixed_k, intrinsics_dir = None, None
+    if intrinsics_path:
+        if os.path.isfile(intrinsics_path):
+            fixed_k = load_intrinsics(intrinsics_path)
+        elif os.path.isdir(intrinsics_path):
+            intrinsics_dir = intrinsics_path
+        else:
+            print(f"[Warning] invalid intrinsics path: {intrinsics_path}")
+    if hamer is None:
+        hamer = hamer_inference(hamer_opt)
+    for img_path in _list_images(input_folder):
+        file_name = os.path.splitext(os.path.basename(img_path))[0]
+        image_results = {'left': None, 'right': None}
+        bbox_coords = get_bbox_from_npy(os.path.join(mask_folder, f"{file_name}.npy"), target_val=3)
+        if bbox_coords is None:
+            continue
+        current_k_real = None
+        if fixed_k is not None:
+            current_k_real = fixed_k
+        elif intrinsics_dir is not None:
+            txt_path = os.path.join(intrinsics_dir, f"{file_name}.txt")
+            if os.path.exists(txt_path):
+                current_k_real = load_intrinsics(txt_path)
+        try:
+            image = _imread_bgr(img_path)
+            if image is None:
+                continue
+            try:
+                output, _ = hamer.estimate_from_rgb(image, [['right', bbox_coords]], current_k_real)
+                image_results['right'] = hand_record(output, True, 0)
+            except Exception as e_inner:
+                print(f"Error processing hand in {file_name}: {e_inner}")
+            np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
+        except Exception as e:
+            print(f"Error processing file {img_path}: {e}")
+            continue
+
+
 def write_obj(path: str, vertices: np.ndarray, faces: np.ndarray):
     with open(path, "w") as f:
         for v in vertices:

@@ -108,3 +108,69 @@ def test_npy_record_and_obj_reconstruction(hi, tmp_path):
     np.testing.assert_allclose(v[:778], out["pred_vertices"][0].cpu().numpy() + rec["right"]["cam_t"], atol=2e-4)
     left = out["pred_vertices"][1].cpu().numpy().copy(); left[:, 0] *= -1
     np.testing.assert_allclose(v[778:], left + rec["left"]["cam_t"], atol=2e-4)
+
+
+class _FixedDetector:
+    """Detector stand-in for the batch drivers: the boxes are given (the detector has its own tests)."""
+
+    def __init__(self, dets):
+        self.dets = dets
+
+    def detect(self, image):
+        return [None], [self.dets]
+
+
+def test_process_batch_npz_and_mask_driver(hi, tmp_path):
+    """The two remaining savers of infer.py: process_batch (:908-1036, rotation matrices in one .npz per hand, suffix rule
+    for repeated labels) and process_batch_manopara_with_mask (:1099-1220, box from label 3 of a mask, per-frame
+    intrinsics), plus the OBJ -> reprojection helpers of hamer/reconstruct.py."""
+    from PIL import Image
+    from hamer_yolo_amd.hamer.reconstruct import load_obj, project_vertices
+    from hamer_yolo_amd.infer import get_bbox_from_npy, process_batch, process_batch_manopara_with_mask
+    img_dir, out_dir, mask_dir, k_dir = tmp_path / "rgb", tmp_path / "out", tmp_path / "mask", tmp_path / "k"
+    for d in (img_dir, mask_dir, k_dir):
+        d.mkdir()
+    frame = synth.frame_u8(480, 640, seed=5).numpy()
+    Image.fromarray(frame[:, :, ::-1]).save(img_dir / "f0.png")
+    dets = [["right", [100.0, 120.0, 260.0, 300.0]], ["left", [380.0, 200.0, 520.0, 330.0]], ["right", [300.0, 20.0, 420.0, 150.0]]]
+    K = np.array([[600.0, 0, 320], [0, 610.0, 240], [0, 0, 1]], np.float32)
+    process_batch(str(img_dir), str(out_dir), K, hamer=hi, detector=_FixedDetector(dets))
+    names = sorted(os.listdir(out_dir))
+    assert names == ["f0_left.npz", "f0_right.npz", "f0_right_2.npz"]
+    out, _ = hi.estimate_from_rgb(frame, dets, K)
+    for name, i in (("f0_right.npz", 0), ("f0_left.npz", 1), ("f0_right_2.npz", 2)):
+        z = np.load(out_dir / name)
+        assert z["betas"].shape == (1, 10) and z["global_orient"].shape == (1, 1, 3, 3) and z["hand_pose"].shape == (1, 15, 3, 3)
+        assert z["cam_t"].shape == (1, 3) and bool(z["is_right"]) == (dets[i][0] == "right")
+        np.testing.assert_allclose(z["hand_pose"][0], out["pred_mano_params"]["hand_pose"][i].cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(z["cam_t"][0], out["pred_cam_t_full"][i].cpu().numpy(), atol=1e-6)
+
+    # mask-driven: label 3 occupies rows 150..280, cols 200..330 -> box [200, 150, 330, 280]
+    mask = np.zeros((480, 640), np.uint8)
+    mask[150:281, 200:331] = 3
+    mask[10:20, 10:20] = 2
+    np.save(mask_dir / "f0.npy", mask)
+    assert get_bbox_from_npy(str(mask_dir / "f0.npy")) == [200.0, 150.0, 330.0, 280.0]
+    assert get_bbox_from_npy(str(mask_dir / "f0.npy"), target_val=7) is None
+    assert get_bbox_from_npy(str(mask_dir / "missing.npy")) is None
+    np.savetxt(k_dir / "f0.txt", K)
+    mout = tmp_path / "mout"
+    process_batch_manopara_with_mask(str(img_dir), str(mask_dir), str(mout), str(k_dir), hamer=hi)
+    rec = np.load(mout / "f0.npy", allow_pickle=True).item()
+    assert rec["left"] is None and rec["right"]["is_right"] is True
+    ref, _ = hi.estimate_from_rgb(frame, [["right", [200.0, 150.0, 330.0, 280.0]]], K)
+    want = hand_record(ref, True, 0)
+    for k in ("betas", "theta", "cam_t"):
+        np.testing.assert_allclose(rec["right"][k], want[k], atol=1e-6)
+
+    # .npy -> OBJ -> reprojection: every projected vertex of the reconstructed mesh lands where the network's
+    # camera-frame vertices project
+    reconstruct_and_save_obj_with_wrapper(str(mout), str(tmp_path / "obj"), hi)
+    v, f = load_obj(str(tmp_path / "obj" / "f0.obj"))
+    assert v.shape == (778, 3) and f.shape == (1538, 3) and f.min() == 0 and f.max() == 777
+    px, order = project_vertices(v, f, K)
+    cam = ref["pred_vertices"][0].cpu().numpy().astype(np.float64) + want["cam_t"]
+    uv = (K.astype(np.float64) @ cam.T).T
+    np.testing.assert_allclose(px, (uv[:, :2] / uv[:, 2:3]).astype(np.int32), atol=1)
+    assert sorted(order.tolist()) == list(range(1538))
+    assert load_obj(str(tmp_path / "nope.obj")) == (None, None)
