@@ -609,6 +609,143 @@ int launch_fp8(const KArgs& g, hipStream_t s) {
   return hm_check_launch("hm_gemm_fp8");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Deep-prefetch variant of the 256x256 tile (plain GEMM, 16-bit operands).  With a 2-stage ring the LDS-DMA of one
+// K-step (64 KB) is all that is in flight, and the K loop runs at the latency of that burst (~1.6 us per step against
+// 0.95 us of MFMA work; a 256x128 tile with 3 stages reaches the same FLOP rate with 1.5x the bytes per flop: the fill
+// is bound by bytes in flight, not by a byte rate).  Two full stages are 128 KB of the 160 KB LDS; the remaining 32 KB
+// are exactly one more X tile, so here X runs through a ring of THREE slots and is fetched two K-steps ahead (W: two
+// slots, one step ahead): 96 KB in flight.  That uses every byte of LDS, so the per-column epilogue vectors wait in a
+// register per thread and are written to LDS after the K loop.  All copies are issued from inline asm (saddr form:
+// uniform base + 32-bit lane offset) and vmcnt is counted by hand: at the top of step t all but the newest 4 copies
+// (X of step t+1, issued after W(t) in step t-1) must have landed.
+// saddr forms: address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+__device__ __forceinline__ void glds16_hidden_s(const char* base, unsigned off, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+}
+
+template <class T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const KArgs g) {
+  constexpr int WM = 4, WN = 2, MI = 4, NI = 8, NW = 8, BM = 256, BN = 256, BK = 64, ROWB = 128;
+  constexpr int TILE_BYTES = 256 * ROWB;                               // 32 KB
+  constexpr int XRING = 0, WRING = 3 * TILE_BYTES;                      // X slots 0..2 | W slots 0..1  (= 160 KB)
+  constexpr int XI = 4, WI = 4;                      // 1-KiB pieces (8 rows x 128 B) per wave and operand per K-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using vec8 = typename T::vec8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wr = wave / WN, wc = wave % WN;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+
+  const int srow = lane >> 3, swz = (lane & 7) ^ (srow & 7);
+  unsigned xoff[XI], woff[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    int gm = m0 + wave * XI * 8 + i * 8 + srow;
+    gm = gm < g.M ? gm : g.M - 1;
+    xoff[i] = (unsigned)gm * (unsigned)(g.ldx * 2) + swz * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int gn = n0 + wave * WI * 8 + i * 8 + srow;
+    gn = gn < g.N ? gn : g.N - 1;
+    woff[i] = (unsigned)gn * (unsigned)(g.ldw * 2) + swz * 16;
+  }
+  auto dma_x = [&](int slot, int kt) {
+    const char* base = X + (size_t)kt * ROWB;
+    char* l = smem + XRING + slot * TILE_BYTES + wave * XI * 1024;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) glds16_hidden_s(base, xoff[i], l + i * 1024);
+  };
+  auto dma_w = [&](int slot, int kt) {
+    const char* base = W + (size_t)kt * ROWB;
+    char* l = smem + WRING + slot * TILE_BYTES + wave * WI * 1024;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) glds16_hidden_s(base, woff[i], l + i * 1024);
+  };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fsw = lane & 7, fch = lane >> 4;
+  auto substep = [&](int xslot, int wslot, int ks) {
+    const char* lx = smem + XRING + xslot * TILE_BYTES;
+    const char* lw = smem + WRING + wslot * TILE_BYTES;
+    const int coff = ((ks * 4 + fch) ^ fsw) * 16;
+    vec8 wf[NI], xf[MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int nk = g.K / BK;
+  // prologue: X(0), W(0), X(1) in flight; this thread's column of the bias waits in a register for the epilogue
+  dma_x(0, 0);
+  dma_w(0, 0);
+  if (nk > 1) dma_x(1, 1);
+  float bias_reg = 0.f;
+  if (tid < BN && g.bias) bias_reg = g.bias[min(n0 + tid, g.N - 1)];
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias_reg) :: "memory");    // (also retires the bias load before any counted wait)
+
+  int xs = 0;                                          // X slot of step kt = kt % 3
+  for (int kt = 0; kt < nk; ++kt) {
+    // step kt-1 issued W(kt) then X(kt+1): all but the newest 4 copies have landed = W(kt) and the older X(kt)
+    if (kt >= 1) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                      // step kt complete in LDS; everyone is done reading step kt-1's slots
+    const int xs2 = xs == 0 ? 2 : xs - 1;              // (kt + 2) % 3 = the slot step kt-1 read
+    substep(xs, kt & 1, 0);
+    if (kt + 1 < nk) dma_w((kt + 1) & 1, kt + 1);      // W first, then X: the counted wait above relies on this order
+    if (kt + 2 < nk) dma_x(xs2, kt + 2);
+    substep(xs, kt & 1, 1);
+    xs = xs == 2 ? 0 : xs + 1;
+  }
+
+  __builtin_amdgcn_s_barrier();                        // the ring is free: per-column vectors, then epilogue staging
+  constexpr int EPI_BYTES = NW * epi_stage_bytes(MI, NI);
+  float2* rowstat = (float2*)(smem + EPI_BYTES);       // unused by these epilogues
+  float* colvec = (float*)(rowstat + BM);
+  if (tid < BN) colvec[tid] = bias_reg;
+  __builtin_amdgcn_s_barrier();
+  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI),
+                           rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI, 0);
+}
+
+template <class T, int EPI>
+int launch_rs(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 5 * 256 * 128;                                    // 163,840 B: all of it
+  static_assert(LDS >= 8 * epi_stage_bytes(4, 8) + 256 * 8 + 2 * 256 * 4, "epilogue staging + vectors fit");
+  auto kern = gemm_x3_kernel<T, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return hm_set_error(HM_ERR_HIP, "gemm: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, g);
+  return hm_check_launch("hm_gemm");
+}
+
 // partial (sum, sum of squares) per 64 columns [P][M][2] -> (mean, rstd) per row [M][2]
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ fin, int M, int P,
                                                           float invD, float eps) {
@@ -667,6 +804,11 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
     case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
     case 18: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 97>(g, s, "hm_gemm"); // EXPERIMENT (wrong results): every tile loads operand panel 0 (pure L2 hits)
+    case 24:                                                                           // X two K-steps ahead in a 3-slot ring (gemm_x3_kernel)
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
+        if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_rs<T, EPI>(g, s);   // 32-bit lane offsets
+      }
+      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
     case 16: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 94>(g, s, "hm_gemm"); // EXPERIMENT: fill only, tile-major operands
     case 17: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 95>(g, s, "hm_gemm"); // EXPERIMENT: full kernel, tile-major operands
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
@@ -695,7 +837,7 @@ int pick_variant(const KArgs& g) {
   }
   if (g_variant >= 0) return g_variant;
   if (g.M < 1024 || g.N < 512) return 0;
-  return g.K >= 2560 ? 9 : 10;
+  return g.K >= 2560 ? 9 : 10;     // (variant 24, X two K-steps ahead: -2 % per GEMM in isolation, nothing over a whole step)
 }
 
 template <class T>
@@ -747,7 +889,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (v < -1 || v > 23) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) .. 15 (12..15: timing ablations)");
+  if (v < -1 || v > 24) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) .. 15 (12..15: timing ablations)");
   g_variant = v;
   return HM_OK;
 }

@@ -62,6 +62,29 @@ def test_gemm_tile_variants_exact(variant):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_deep_prefetch_variant_exact(dt):
+    """gemm_x3_kernel (variant 24: X three-slot ring, two K-steps ahead, hand-counted vmcnt) on exact-integer data through
+    the residual epilogue: bit-exact for 1, 2, 3 and many K-steps, ragged M / N, and repeated launches (race screen)."""
+    lib = L.load()
+    try:
+        L.check(lib.hm_gemm_set_variant(24))
+        for (M, N, K) in ((300, 260, 64), (513, 388, 128), (1000, 1284, 192), (700, 516, 448), (257, 260, 1280), (1536, 512, 5120)):
+            x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+            w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+            bias = (torch.arange(N) % 9 - 4).float()
+            resid = ((torch.arange(M * N).reshape(M, N) * 3) % 11 - 5).float()
+            ref = x @ w.t() + bias + resid
+            xd, wd, bd, rd = x.to(DEV, dt), w.to(DEV, dt), bias.to(DEV), resid.to(DEV)
+            for _ in range(4):
+                out = ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd)
+                assert torch.equal(out.cpu(), ref), (M, N, K)
+            o16 = ops.gemm(xd, wd, bd, L.HM_EPI_STORE)
+            assert torch.equal(o16.float().cpu(), (x @ w.t() + bias).to(dt).float()), (M, N, K)
+    finally:
+        lib.hm_gemm_set_variant(-1)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(384, 1280, 768), (192, 3840, 1280), (200, 132, 64), (64, 6144, 1280), (1, 4, 64)])
 def test_gemm_epilogues(M, N, K, dt):
     x = _u("gx", (M, K), 1.0, seed=M).to(dt)
