@@ -176,7 +176,9 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         if (LNIN) st = rowstat[row];
         if (m >= g.M || n >= g.N) continue;
         if (LNIN) { v0 = (v0 - st.x * cs0) * st.y; v1 = (v1 - st.x * cs1) * st.y; }
-        v0 += bi0; v1 += bi1;
+        // (__fadd_rn: never contracted into the activation's first multiply, so every tile shape rounds alike)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0[q] = __fadd_rn(v0[q], bi0[q]); v1[q] = __fadd_rn(v1[q], bi1[q]); }
         if constexpr (MX8) {
           // MXFP8 out: this lane's 8 columns and its 3 quad neighbours' form one 32-column block of row m (N % 64 == 0,
           // so a row's lanes are all in or all out: the quad reduction sees no inactive lane)
@@ -257,7 +259,11 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         f32x4_t r = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (RES) r = *(const f32x4_t*)(rlds + row * RS + rslot * 16);
         if (m >= g.M || n >= g.N) continue;
-        v += *(const f32x4_t*)(cbias + (n - nb));
+        {
+          const f32x4_t bi = *(const f32x4_t*)(cbias + (n - nb));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = __fadd_rn(v[q], bi[q]);
+        }
         if (EPI == HM_EPI_GELU) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
@@ -856,10 +862,15 @@ int launch_gemm_epi(const KArgs& g, int epilogue, hipStream_t s) {
   }
 }
 
+// N-tile of the convolution: as wide as Cout allows (128 / 64 / 32 columns), but narrower when that leaves most CUs without a
+// tile -- the 12x20 and 24x40 maps of the YOLOv7 head have 30-120 row tiles per 16 frames, and K = 2304..4608 is long
 template <class T, int EPI>
 int launch_conv_ni(const KArgs& g, hipStream_t s) {
-  if (g.N > 64) return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true>(g, s, "hm_conv2d_nhwc");
-  if (g.N > 32) return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true>(g, s, "hm_conv2d_nhwc");
+  const int tiles_m = (g.M + 127) / 128;
+  int bn = g.N > 64 ? 128 : (g.N > 32 ? 64 : 32);
+  while (bn > 32 && tiles_m * ((g.N + bn - 1) / bn) < 192) bn >>= 1;
+  if (bn == 128) return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true>(g, s, "hm_conv2d_nhwc");
+  if (bn == 64) return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true>(g, s, "hm_conv2d_nhwc");
   return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true>(g, s, "hm_conv2d_nhwc");
 }
 
