@@ -339,8 +339,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     } else {
       pix_y[i] = pix_x[i] = 0;
       xsrc[i] = X + (size_t)gm * g.ldx + chunk * 8;
-      if (SCHED >= 94)   // experiment: tile-major operand [M/BM][K/BK][BM][BK] (timing only)
-        xsrc[i] = X + (size_t)(m0 / BM) * (g.K / BK) * BM * BK + (size_t)(wave * XI * RPI + i * RPI + srow) * BK + chunk * 8;
     }
   }
 #pragma unroll
@@ -348,8 +346,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     int gn = (SCHED == 97 ? 0 : n0) + wave * WI * RPI + i * RPI + srow;
     gn = gn < g.N ? gn : g.N - 1;
     wsrc[i] = W + (size_t)gn * g.ldw + chunk * 8;
-    if (SCHED >= 94)
-      wsrc[i] = W + (size_t)(n0 / BN) * (g.K / BK) * BN * BK + (size_t)(wave * WI * RPI + i * RPI + srow) * BK + chunk * 8;
   }
 
   auto stage = [&](int buf, int kt) {
@@ -369,10 +365,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < XI; ++i) glds16(xsrc[i] + (SCHED >= 94 ? (size_t)kt * BM * BK : (size_t)kt * BK), lx + i * 1024);
+      for (int i = 0; i < XI; ++i) glds16(xsrc[i] + (size_t)kt * BK, lx + i * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < WI; ++i) glds16(wsrc[i] + (SCHED >= 94 ? (size_t)kt * BN * BK : (size_t)kt * BK), lw + i * 1024);
+    for (int i = 0; i < WI; ++i) glds16(wsrc[i] + (size_t)kt * BK, lw + i * 1024);
   };
 
   f32x4_t acc[NI][MI];
@@ -385,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   const int frow = lane & 15, fsw = BK == 64 ? (lane & 7) : ((lane >> 2) & 3), fch = lane >> 4;
   // one K sub-step (32 deep): fragment reads + NI x MI MFMAs
   auto substep = [&](int buf, int ks) {
-    if (SCHED == 92 || SCHED == 94) return;             // ablation: LDS-DMA fill only
+    if (SCHED == 92) return;                            // ablation: LDS-DMA fill only
     const char* lx = smem + buf * STAGE_BYTES;
     const char* lw = lx + XTILE_BYTES;
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
@@ -394,13 +390,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
 #pragma unroll
     for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
-    if (SCHED == 91) {                                  // ablation: keep the fragment reads alive, skip the MFMAs
-#pragma unroll
-      for (int i = 0; i < NI; ++i) asm volatile("" :: "v"(wf[i]));
-#pragma unroll
-      for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(xf[i]));
-      return;
-    }
     if (SCHED >= 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -437,10 +426,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   int rd = 0, wrb = STAGES - 1;                        // ring slots: read tile kt, write tile kt+STAGES-1
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed: in steady state the STAGES-2 newer tiles may still be in flight
-    if (SCHED != 90) {                                 // (90: ablation, never wait -- timing only)
-      if (kt + STAGES - 2 < nk) wait_vmcnt<LOADS * (STAGES - 2)>();
-      else wait_vmcnt<0>();
-    }
+    if (kt + STAGES - 2 < nk) wait_vmcnt<LOADS * (STAGES - 2)>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                      // everyone's tile kt landed; everyone is done reading slot wrb
     const bool more = kt + STAGES - 1 < nk;
     if (SCHED <= 1) {                                  // loads first, then the whole tile
@@ -801,8 +788,6 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 9: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 1>(g, s, "hm_gemm");   // + s_setprio around the MFMA cluster
     case 10: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");  // + loads issued between the two sub-steps
     case 11: return launch_cfg<T, EPI, 4, 2, 4, 8, 4, false, 32, 1>(g, s, "hm_gemm");  // 256x256x32, 4 stages, setprio
-    case 12: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 90>(g, s, "hm_gemm"); // ABLATION (wrong results): loads never waited
-    case 13: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 91>(g, s, "hm_gemm"); // ABLATION (wrong results): no MFMA
     case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // ABLATION: LDS-DMA + waits + barriers only
     case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ABLATION: ds_read + MFMA + barriers, no loads
     case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // ABLATION: no epilogue
@@ -815,8 +800,6 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
         if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_rs<T, EPI>(g, s);   // 32-bit lane offsets
       }
       return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
-    case 16: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 94>(g, s, "hm_gemm"); // EXPERIMENT: fill only, tile-major operands
-    case 17: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 95>(g, s, "hm_gemm"); // EXPERIMENT: full kernel, tile-major operands
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
   }
 }
@@ -900,7 +883,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (v < -1 || v > 24) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) .. 15 (12..15: timing ablations)");
+  if (v < -1 || v > 24) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..24 (14, 15, 18, 20: timing ablations with wrong results)");
   g_variant = v;
   return HM_OK;
 }

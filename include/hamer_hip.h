@@ -73,7 +73,8 @@ typedef struct hm_gemm_args {
 int hm_gemm(const hm_gemm_args* args, void* stream);
 /* HM_EPI_RESID_LN partials [D/64][M][2] -> row_stats [M][2] = (mean, 1/sqrt(var + eps)) for HM_EPI_LN_*. */
 int hm_ln_finalize(const float* partials, float* row_stats, int M, int D, float eps, void* stream);
-/* Tuning hook: pin the GEMM tile configuration (0..5, see gemm.hip); -1 restores the default
+/* Tuning hook: pin the GEMM tile configuration (see launch_gemm in gemm.hip; 14, 15, 18, 20 are timing ablations that
+ * compute wrong results); -1 restores the default
  * (also settable through the HM_GEMM_VARIANT environment variable).  Results do not depend on it
  * beyond fp32 summation order. */
 int hm_gemm_set_variant(int variant);
