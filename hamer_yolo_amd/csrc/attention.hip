@@ -61,10 +61,17 @@ __device__ __forceinline__ void wait_vm0() {
   asm volatile("" ::: "memory");
 }
 
-template <class TT>
+// MX8: the output is the MXFP8 operand of an fp8 proj GEMM instead of 16-bit rows.  A head's 80 columns do not align with
+// 32-element scale blocks, so each head is widened to HDP = 96 columns (3 blocks, the last 16 columns zero): out8 is
+// [B*T][heads*96] e4m3 bytes, out_scales [heads*3][B*T] E8M0 -- the proj weight is laid out with the same K order.
+constexpr int HDP = 96;
+typedef __attribute__((ext_vector_type(4))) int v4i_att;
+
+template <class TT, bool MX8 = false>
 __global__ __launch_bounds__(64 * NWAVE, 3) void vit_attention_kernel(const typename TT::elem* __restrict__ qkv,
                                                                     typename TT::elem* __restrict__ out, int heads,
-                                                                    int items, float scale_log2e) {
+                                                                    int items, float scale_log2e,
+                                                                    unsigned char* __restrict__ out_scales = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using elem = typename TT::elem;
   using vec8 = typename TT::vec8;
@@ -194,6 +201,49 @@ __global__ __launch_bounds__(64 * NWAVE, 3) void vit_attention_kernel(const type
     }
     // through this wave's LDS tile: the accumulator layout gives 8 bytes per lane and 32-byte runs per row; written
     // from LDS a lane carries 16 bytes and a row leaves as one 160-byte run (3 store instructions instead of 5)
+    if constexpr (MX8) {
+      const int Mrows = (items / heads) * T;
+      // block amax over this lane's values, then over the 4 lane groups that share query li
+      float am[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) am[dt >> 1] = fmaxf(am[dt >> 1], fabsf(oacc[dt][r] * inv));
+      unsigned sb[3];
+      float isc[3];
+#pragma unroll
+      for (int bk = 0; bk < 3; ++bk) {
+        float a = am[bk];
+        a = fmaxf(a, __shfl_xor(a, 16, 64));
+        a = fmaxf(a, __shfl_xor(a, 32, 64));
+        sb[bk] = mx8_scale_byte(a);
+        isc[bk] = mx8_inv_scale(sb[bk]);
+      }
+      char* ot8 = smem + 2 * BUF_BYTES + wave * OTILE_BYTES;            // [16][96] bytes (1.5 KB of the 2.5 KB tile)
+#pragma unroll
+      for (int dt = 0; dt < 6; ++dt) {
+        int p = 0;
+        if (dt < 5) {
+          const float sc = inv * isc[dt >> 1];
+          p = mx8_pack4(oacc[dt][0] * sc, oacc[dt][1] * sc, oacc[dt][2] * sc, oacc[dt][3] * sc);
+        }
+        *(int*)(ot8 + li * HDP + dt * 16 + 4 * g) = p;
+      }
+      char* obase8 = (char*)out + ((size_t)b * T + wave * 16) * (heads * HDP) + h * HDP;
+#pragma unroll
+      for (int c0 = 0; c0 < 16 * (HDP / 16); c0 += 64) {
+        const int c = c0 + lane;
+        if (c < 16 * (HDP / 16)) {
+          const int row = c / (HDP / 16), ch = c % (HDP / 16);
+          *(v4i_att*)(obase8 + (size_t)row * (heads * HDP) + ch * 16) = *(const v4i_att*)(ot8 + row * HDP + ch * 16);
+        }
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int bk = 0; bk < 3; ++bk) out_scales[(size_t)(h * 3 + bk) * Mrows + (size_t)b * T + q] = (unsigned char)sb[bk];
+      }
+      return;
+    }
     elem* ot = (elem*)(smem + 2 * BUF_BYTES + wave * OTILE_BYTES);
 #pragma unroll
     for (int dt = 0; dt < 5; ++dt) {
@@ -240,11 +290,11 @@ __global__ __launch_bounds__(64 * NWAVE, 3) void vit_attention_kernel(const type
   }
 }
 
-template <class TT>
-int launch_att(const void* qkv, void* out, int B, int heads, float scale, hipStream_t s) {
+template <class TT, bool MX8 = false>
+int launch_att(const void* qkv, void* out, int B, int heads, float scale, hipStream_t s, void* out_scales = nullptr) {
   static bool attr_set = false;
   static int n_cu = 0;
-  auto kern = vit_attention_kernel<TT>;
+  auto kern = vit_attention_kernel<TT, MX8>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
       return hm_set_error(HM_ERR_HIP, "hm_vit_attention: cannot raise dynamic LDS limit");
@@ -259,7 +309,7 @@ int launch_att(const void* qkv, void* out, int B, int heads, float scale, hipStr
   // persistent: one workgroup per CU, every workgroup the same number of items when items % CUs == 0
   const int per = (items + n_cu - 1) / n_cu, grid = (items + per - 1) / per;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWAVE), ATT_LDS, s, (const typename TT::elem*)qkv,
-                     (typename TT::elem*)out, heads, items, scale * 1.44269504088896340736f);
+                     (typename TT::elem*)out, heads, items, scale * 1.44269504088896340736f, (unsigned char*)out_scales);
   return hm_check_launch("hm_vit_attention");
 }
 
@@ -276,4 +326,15 @@ extern "C" int hm_vit_attention(const void* qkv, void* out, int B, int tokens, i
   if (dtype == HM_DTYPE_BF16) return launch_att<TBf16>(qkv, out, B, heads, scale, s);
   if (dtype == HM_DTYPE_F16) return launch_att<TF16>(qkv, out, B, heads, scale, s);
   return hm_set_error(HM_ERR_ARG, "hm_vit_attention: bad dtype");
+}
+
+extern "C" int hm_vit_attention_mx8(const void* qkv, void* out8, void* out_scales, int B, int tokens, int heads, int head_dim,
+                                    float scale, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!qkv || !out8 || !out_scales || B <= 0 || heads <= 0) return hm_set_error(HM_ERR_ARG, "hm_vit_attention_mx8: bad arguments");
+  if (tokens != T || head_dim != HD)
+    return hm_set_error(HM_ERR_ARG, "hm_vit_attention_mx8: built for 192 tokens and head_dim 80 (ViT-H/16 on 256x192)");
+  if (((uintptr_t)qkv | (uintptr_t)out8 | (uintptr_t)out_scales) & 15) return hm_set_error(HM_ERR_ARG, "hm_vit_attention_mx8: 16-byte alignment");
+  HmProfScope prof(HM_K_ATTENTION, 1, B, heads, head_dim, s);
+  return launch_att<TBf16, true>(qkv, out8, B, heads, scale, s, out_scales);
 }

@@ -11,7 +11,7 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, hs, mlps, partials, total;
+  size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, hs, mlps, atts, partials, total;
   int ksplit_proj, ksplit_fc2;
 };
 
@@ -50,6 +50,7 @@ Layout make_layout(const hm_hamer_weights& w, int B) {
   L.rowstats = o; o += align256(M * 8);                      // (mean, rstd) per row
   L.hs = o; o += align256(((D + 31) / 32) * M);               // fp8 path: E8M0 scales of the MXFP8 LayerNorm output [D/32][M]
   L.mlps = o; o += align256((((size_t)w.mlp_dim + 31) / 32) * M);   // ... and of the GELU output [mlp/32][M]
+  L.atts = o; o += align256((size_t)w.heads * 3 * M);           // ... and of the attention output [heads*3][M] (fp8 proj)
   // split-K of the two N = D GEMMs of a block when their 128x128 tiles would leave most CUs idle (a few hands)
   L.ksplit_proj = pick_split_k((int)M, (int)D, (int)D);
   L.ksplit_fc2 = pick_split_k((int)M, (int)D, w.mlp_dim);
@@ -131,7 +132,9 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
     const hm_vit_block& b = w->blocks[i];
     fp8 = b.qkv_w8 && b.qkv_ws && b.fc1_w8 && b.fc1_ws && b.fc2_w8 && b.fc2_ws;
   }
-  void *hs = ws + L.hs, *mlps = ws + L.mlps;
+  void *hs = ws + L.hs, *mlps = ws + L.mlps, *atts = ws + L.atts;
+  bool fp8_proj = fp8 && D / w->heads == 80;            // att (16-bit [M][D]) has room for the widened [M][heads*96] bytes
+  for (int i = 0; i < w->depth && fp8_proj; ++i) fp8_proj = w->blocks[i].proj_w8 && w->blocks[i].proj_ws;
   auto gemm8 = [&](const void* X8, const void* xsc, int K, const void* W8, const float* wsc, int N, void* C, int ldc,
                    const float* bias, int epi, const float* resid, void* out_scales) {
     hm_gemm_fp8_args g{};
@@ -157,8 +160,13 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
       // h / mlp hold e4m3 bytes here (half of their 16-bit size), hs / mlps the block scales
       HM_TRY(hm_layernorm_mx8(x, b.ln1_g, b.ln1_b, h, hs, M, D, w->vit_eps, stream));
       HM_TRY(gemm8(h, hs, D, b.qkv_w8, b.qkv_ws, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, nullptr));
-      HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
-      HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, D, 0));
+      if (fp8_proj) {
+        HM_TRY(hm_vit_attention_mx8(qkv, att, atts, B, tokens, w->heads, D / w->heads, scale, stream));
+        HM_TRY(gemm8(att, atts, w->heads * 96, b.proj_w8, b.proj_ws, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, nullptr));
+      } else {
+        HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
+        HM_TRY(gemm(att, D, b.proj_w, D, D, x, D, b.proj_b, HM_EPI_RESID_F32, x, D, 0));
+      }
       HM_TRY(hm_layernorm_mx8(x, b.ln2_g, b.ln2_b, h, hs, M, D, w->vit_eps, stream));
       HM_TRY(gemm8(h, hs, D, b.fc1_w8, b.fc1_ws, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU_MX8, nullptr, mlps));
       HM_TRY(gemm8(mlp, mlps, w->mlp_dim, b.fc2_w8, b.fc2_ws, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, nullptr));

@@ -89,6 +89,11 @@ class HamerEngine:
                 b.qkv_w8, b.qkv_ws = w8(sd[p + "attn.qkv.weight"])
                 b.fc1_w8, b.fc1_ws = w8(sd[p + "mlp.fc1.weight"])
                 b.fc2_w8, b.fc2_ws = w8(sd[p + "mlp.fc2.weight"])
+                if v.head_dim == 80:                 # proj too: K reordered to 96 columns per head (hm_vit_attention_mx8)
+                    wp = sd[p + "attn.proj.weight"].detach().to(self.device, torch.float32)
+                    wpad = torch.zeros(D, v.heads, 96, device=self.device)
+                    wpad[:, :, :80] = wp.reshape(D, v.heads, 80)
+                    b.proj_w8, b.proj_ws = w8(wpad.reshape(D, v.heads * 96))
             if self.fold_ln:
                 cs, bl = ln_fold(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], sd[p + "norm1.weight"], sd[p + "norm1.bias"])
                 b.qkv_colsum, b.qkv_bias_ln = L.ptr(cs), L.ptr(bl)

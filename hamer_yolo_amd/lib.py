@@ -21,7 +21,7 @@ EXPORTS = [
     "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
-    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_hamer_forward_split", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8",
+    "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_hamer_forward_split", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -61,7 +61,7 @@ class VitBlock(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "proj_w", "fc1_w", "fc2_w",
                                   "qkv_b", "proj_b", "fc1_b", "fc2_b",
                                   "qkv_colsum", "qkv_bias_ln", "fc1_colsum", "fc1_bias_ln",
-                                  "qkv_w8", "fc1_w8", "fc2_w8", "qkv_ws", "fc1_ws", "fc2_ws")]
+                                  "qkv_w8", "fc1_w8", "fc2_w8", "qkv_ws", "fc1_ws", "fc2_ws", "proj_w8", "proj_ws")]
 
 
 class DecLayer(C.Structure):
@@ -139,6 +139,7 @@ def load() -> C.CDLL:
     lib.hm_ln_finalize.argtypes = [vp, vp, i, i, C.c_float, vp]
     lib.hm_gemm_fp8.argtypes = [C.POINTER(GemmFp8Args), vp]
     lib.hm_layernorm_mx8.argtypes = [vp, vp, vp, vp, vp, i, i, C.c_float, vp]
+    lib.hm_vit_attention_mx8.argtypes = [vp, vp, vp, i, i, i, i, C.c_float, vp]
     lib.hm_layernorm_accum.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, C.c_float, vp]
     lib.hm_conv2d_nhwc.argtypes = [C.POINTER(ConvArgs), vp]
     lib.hm_maxpool_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, i, vp]

@@ -141,6 +141,17 @@ def vit_attention(qkv: torch.Tensor, B: int, tokens: int, heads: int, head_dim: 
     return out
 
 
+def vit_attention_mx8(qkv: torch.Tensor, B: int, tokens: int, heads: int, head_dim: int, scale: float):
+    """Attention with MXFP8 output: (out8 (B*tokens, heads*96) uint8, scales (heads*3, B*tokens) uint8)."""
+    _dev(qkv)
+    assert qkv.shape == (B * tokens, 3 * heads * head_dim) and qkv.is_contiguous() and qkv.dtype == torch.bfloat16
+    out8 = torch.empty(B * tokens, heads * 96, device=qkv.device, dtype=torch.uint8)
+    scales = torch.empty(heads * 3, B * tokens, device=qkv.device, dtype=torch.uint8)
+    L.check(L.load().hm_vit_attention_mx8(L.ptr(qkv), L.ptr(out8), L.ptr(scales), B, tokens, heads, head_dim, scale,
+                                          L.current_stream()), "hm_vit_attention_mx8")
+    return out8, scales
+
+
 def patch_im2col(img: torch.Tensor, x0: int, win_w: int, patch: int, pad: int, dtype=torch.bfloat16) -> torch.Tensor:
     _dev(img)
     B, Cc, H, Wf = img.shape

@@ -118,6 +118,12 @@ int hm_layernorm_accum(float* x, const float* partials, int n_partials, const fl
 int hm_vit_attention(const void* qkv, void* out, int B, int tokens, int heads, int head_dim, float scale,
                      int dtype, void* stream);
 
+/* Same attention with MXFP8 output for an fp8 proj GEMM (bf16 qkv in).  Heads are widened from 80 to 96 columns so that
+ * scale blocks of 32 never straddle two heads: out8 [B*tokens][heads*96] e4m3 bytes (columns 80..95 of every head zero),
+ * out_scales [heads*3][B*tokens] E8M0.  The proj weight must use the same K order (hm_vit_block.proj_w8). */
+int hm_vit_attention_mx8(const void* qkv, void* out8, void* out_scales, int B, int tokens, int heads, int head_dim, float scale,
+                         void* stream);
+
 /* PatchEmbed.proj im2col (vit.py:168-176, called on x[:, :, :, 32:-32] at hamer.py:119):
  * img [B][3][img_h][img_w_full] f32, window columns [x0, x0+win_w), conv k=patch, s=patch,
  * zero pad `pad` -> patches [B*gh*gw][3*patch*patch] 16-bit, K order (c, ky, kx). */
@@ -190,6 +196,10 @@ typedef struct hm_vit_block {
    * GEMMs through hm_gemm_fp8 with MXFP8 activations (hm_layernorm_mx8, HM_EPI_GELU_MX8); proj stays 16-bit. */
   const void *qkv_w8, *fc1_w8, *fc2_w8;
   const float *qkv_ws, *fc1_ws, *fc2_ws;
+  /* optional on top of those: proj in fp8 as well.  proj_w8 is [D][heads*96] e4m3, column h*96 + d = proj.weight[:, h*80 + d]
+   * for d < 80 and zero for d >= 80 (the K order of hm_vit_attention_mx8), proj_ws its per-output-channel scale. */
+  const void* proj_w8;
+  const float* proj_ws;
 } hm_vit_block;
 
 typedef struct hm_dec_layer {

@@ -74,6 +74,16 @@ def vit_attention(sd, h: Tensor, p: str, vit, emu=False) -> Tensor:
         q = q * scale
         attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)
         o = attn @ v
+    if emu == "fp8" and vit.head_dim == 80:
+        # fp8 proj: the attention output is MXFP8 with heads widened to 96 columns (3 scale blocks per head, the last
+        # half empty); quantising the zero-padded heads and dropping the padding again is the same arithmetic
+        from . import fp8_ref as Q
+        o32 = (_q(pun, True) @ v) / pun.sum(dim=-1, keepdim=True)             # (B, H, N, 80) fp32, before any rounding
+        opad = torch.zeros(B, vit.heads, N, 96)
+        opad[..., :80] = o32
+        oq = Q.fake_quant_mx8(opad)[..., :80].transpose(1, 2).reshape(B, N, -1)
+        w8, ws = Q.quantize_weight(sd[p + "attn.proj.weight"])
+        return F.linear(oq, Q.dequantize_weight(w8, ws), sd[p + "attn.proj.bias"])
     o = o.transpose(1, 2).reshape(B, N, -1)
     return _linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], emu)
 

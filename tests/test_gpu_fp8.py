@@ -130,3 +130,27 @@ def test_vith_forward_fp8_vs_fp8_oracle(golden_dir):
     assert d_pose < 1e-2 and d_vert < 2e-3
     # against the fp32 reference modules: e4m3 has 3 mantissa bits; this is the accuracy cost of configs[4], not a parity bar
     assert g_pose < 5e-2
+
+
+def test_vit_attention_mx8_matches_16bit_kernel_then_quantised():
+    """hm_vit_attention_mx8 = the attention of hm_vit_attention, taken before the 16-bit rounding, as MXFP8 with every head
+    widened to 96 columns: dequantised it must equal the bf16 kernel's output to e4m3 precision, the pad columns are
+    exact zeros and the scales are those of the oracle quantiser applied to the padded fp32 attention."""
+    B, H, T, d = 3, 16, 192, 80
+    qkv = (_u("aq", (B * T, 3 * H * d), 1.5, seed=11)).to(torch.bfloat16)
+    ref16 = ops.vit_attention(qkv.to(DEV), B, T, H, d, d ** -0.5).float().cpu()                 # (B*T, H*80)
+    o8, os_ = ops.vit_attention_mx8(qkv.to(DEV), B, T, H, d, d ** -0.5)
+    assert o8.shape == (B * T, H * 96) and os_.shape == (H * 3, B * T)
+    deq = Q.mx8_dequantize(o8.cpu(), os_.cpu()).reshape(B * T, H, 96)
+    assert (deq[:, :, 80:] == 0).all() and (o8.cpu().reshape(B * T, H, 96)[:, :, 80:] == 0).all()
+    got = deq[:, :, :80].reshape(B * T, H * 80)
+    blockmax = torch.zeros(B * T, H, 96)
+    blockmax[:, :, :80] = ref16.reshape(B * T, H, 80).abs()
+    blockmax = blockmax.reshape(B * T, H * 3, 32).amax(-1, keepdim=True).expand(-1, -1, 32).reshape(B * T, H, 96)[:, :, :80].reshape(B * T, H * 80)
+    assert ((got - ref16).abs() <= blockmax * 2.0 ** -3 + 1e-6).all()
+    # scales: quantise the (bf16-rounded) reference the same way; a scale may differ only where the block maximum sits on a
+    # power-of-two boundary after the bf16 rounding
+    pad = torch.zeros(B * T, H, 96)
+    pad[:, :, :80] = ref16.reshape(B * T, H, 80)
+    _, rs = Q.mx8_quantize(pad.reshape(B * T, H * 96))
+    assert (os_.cpu() == rs).float().mean().item() > 0.99
