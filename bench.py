@@ -87,24 +87,31 @@ def run_e2e(args, dev, dtype):
     from hamer_yolo_amd.yolo.engine import YoloEngine
     cfg = synth.HamerConfig()
     F = args.frames
-    yolo = YoloEngine(synth.yolo_state_dict(seed=0, nc=3), nc=3, device=dev)
+    nfl = args.in_flight if args.in_flight > 0 else 3
+    ysd = synth.yolo_state_dict(seed=0, nc=3)
+    yolos = [YoloEngine(ysd, nc=3, device=dev) for _ in range(nfl)]      # one activation arena per batch in flight
     eng = HamerEngine(synth.hamer_state_dict(cfg, seed=0, device=dev, bf16_representable=True), synth.mano_params(seed=0), cfg,
                       device=dev, dtype=dtype)
     frames = [synth.frame_u8(1080, 1920, seed=i).to(dev) for i in range(F)]
     boxes = [(400.0, 300.0, 220.0, True), (1500.0, 320.0, 180.0, False), (700.0, 800.0, 260.0, True), (1200.0, 760.0, 160.0, False)]
     rec = ops.crop_boxes([(cx, cy, s * 10.0 / 3.0, fl) for cx, cy, s, fl in boxes]).to(dev)
     mean = 255.0 * np.array([0.485, 0.456, 0.406]); std = 255.0 * np.array([0.229, 0.224, 0.225])
-    img = torch.empty(4 * F, 3, 256, 256, device=dev)
-    out = eng.alloc_outputs(4 * F)
+    imgs = [torch.empty(4 * F, 3, 256, 256, device=dev) for _ in range(nfl)]
+    ctxs = eng.contexts(4 * F, nfl)
     eng.workspace(4 * F)
-    import ctypes as C
+    torch.cuda.synchronize()
+    nstep = [0]
 
-    def step():
-        p = yolo.forward(frames)                                     # one batched pass over all frames of the step
-        yolo.nms_enqueue(p, 0.25, 0.35, [0, 1, 2], True)             # box lists stay on the device: no host sync
-        for i, fr in enumerate(frames):
-            img[4 * i:4 * i + 4] = ops.crop_batch(fr, rec, mean, std)
-        eng.forward(img, out)
+    def step(k=None):
+        k = nstep[0] % nfl if k is None else k
+        nstep[0] += 1
+        c, yolo, img = ctxs[k], yolos[k], imgs[k]
+        with torch.cuda.stream(c.stream):                            # steps alternate between the contexts and overlap
+            p = yolo.forward(frames)                                 # one batched pass over all frames of the step
+            yolo.nms_enqueue(p, 0.25, 0.35, [0, 1, 2], True)         # box lists stay on the device: no host sync
+            for i, fr in enumerate(frames):
+                img[4 * i:4 * i + 4] = ops.crop_batch(fr, rec, mean, std)
+            eng.forward(img, c.out, workspace=c.workspace)
 
     for _ in range(args.warmup):
         step()
@@ -115,7 +122,7 @@ def run_e2e(args, dev, dtype):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     with L.profile(capacity=4096 * 4) as prof:
-        step()
+        step(0)
         torch.cuda.synchronize()
     by = {}
     for kind, epi, M, N, K, ms in prof.records:
@@ -124,7 +131,8 @@ def run_e2e(args, dev, dtype):
                       "value": round(4 * F * args.steps / el, 2), "unit": "hands/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": round(1e3 * el / args.steps, 3), "frames_per_step": F, "frames_per_s": round(F * args.steps / el, 2),
                       "dtype": args.dtype + " (HaMeR) / fp16 (YOLOv7)", "data": "synthetic",
-                      "config": {"workload": "BASELINE configs[2]: 1080p frames, YOLOv7 + 4 fixed boxes/frame + HaMeR"},
+                      "config": {"workload": "BASELINE configs[2]: 1080p frames, YOLOv7 + 4 fixed boxes/frame + HaMeR",
+                                 "batches_in_flight": nfl},
                       "gflop_per_frame": 61.9 + 4 * 251.03, "ms_per_step_by_kernel": {k: round(v, 3) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}}), flush=True)
 
 
@@ -154,6 +162,10 @@ def main():
                          "YOLOv7 + crop + HaMeR with 4 fixed boxes per frame (not a contract line, for DESIGN.md)")
     ap.add_argument("--frames", type=int, default=16, help="e2e: frames per step (hands per step = 4 x frames)")
     ap.add_argument("--split", type=int, default=-1, help="1/0: force the two-stream half-batch schedule on/off (default: engine's choice)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="batches in flight: consecutive steps alternate between this many HIP streams (own workspace and outputs "
+                         "each), so one batch's HBM-bound phases overlap another's MFMA phases; 1 = strictly one after the other; "
+                         "default 2 (crops) / 3 (e2e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -188,13 +200,19 @@ def main():
     img = synth.normalize_crops(synth.crops_u8(B, seed0=rank * B)).to(dev)
     out = eng.alloc_outputs(B)
     eng.workspace(B)
+    ctxs = eng.contexts(B, args.in_flight if args.in_flight > 0 else 2)
+    torch.cuda.synchronize()
 
     split = None if args.split < 0 else bool(args.split)
+    nstep = [0]
 
     def step():
-        eng.forward(img, out, split=split)
-        if world > 1:
-            shard.gather_mano(shard.pack_mano(out), dst=0)
+        c = ctxs[nstep[0] % len(ctxs)]                   # every step is one whole batch; steps alternate between the contexts
+        nstep[0] += 1
+        with torch.cuda.stream(c.stream):
+            eng.forward(img, c.out, split=split, workspace=c.workspace)
+            if world > 1:
+                shard.gather_mano(shard.pack_mano(c.out), dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -214,7 +232,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(out["pred_vertices"]).all()
+    for c in ctxs:
+        assert torch.isfinite(c.out["pred_vertices"]).all()
 
     res = None
     if rank == 0:
@@ -230,7 +249,7 @@ def main():
                                     "decoder and MANO, crops resident in HBM" % B) if args.dtype == "fp8" else
                                    "BASELINE configs[1]: batch=%d synthetic 256x256 crops per GPU, HaMeR ViT-H/16 "
                                    "+ 6-layer decoder + MANO, 16-bit MFMA, crops resident in HBM" % B,
-                       "batch_per_gpu": B, "global_batch": world * B, "weights": "seeded random-init (bf16-representable)",
+                       "batch_per_gpu": B, "global_batch": world * B, "batches_in_flight": len(ctxs), "weights": "seeded random-init (bf16-representable)",
                        "parallelism": f"crop-shard x{world}", "mfma_gflop_per_hand": round(fl["total_mfma"] / 1e9, 2)},
             "model_mfma_frac": round(hands / elapsed * fl["total_mfma"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         }

@@ -123,3 +123,29 @@ def test_split_forward_is_bit_identical(B):
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_batches_in_flight_do_not_interfere():
+    """HamerEngine.contexts: four different batches issued back to back on two contexts (own stream, workspace, outputs)
+    give, each, bit for bit what a lone forward gives."""
+    cfg = synth.tiny_config()
+    sd = synth.hamer_state_dict(cfg, seed=5, device="cuda", bf16_representable=True)
+    eng = HamerEngine(sd, synth.mano_params(seed=5), cfg)
+    B = 6
+    imgs = [synth.normalize_crops(synth.crops_u8(B, seed0=100 + 10 * i)).cuda() for i in range(4)]
+    ref = []
+    for im in imgs:
+        o = eng.forward(im, want_tokens=True)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in o.items()})
+    ctxs = eng.contexts(B, 2, want_tokens=True)
+    got = []
+    for rnd in range(2):
+        for k in range(2):
+            eng.forward_on(ctxs[k], imgs[2 * rnd + k], want_tokens=True)
+        for k in range(2):
+            ctxs[k].stream.synchronize()
+            got.append({n: v.clone() for n, v in ctxs[k].out.items()})
+    for r, g_ in zip(ref, got):
+        for n in r:
+            assert torch.equal(r[n], g_[n]), n
