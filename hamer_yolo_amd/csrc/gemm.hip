@@ -31,6 +31,7 @@ struct KArgs {                                    // kernel-side view of either 
   const float* ln_gamma; void* ln_xg; float* ln_stats; const float* ln_colsum;
   int ln_P;
   const unsigned char* xs; const float* wscale; unsigned char* out_scales;   // hm_gemm_fp8
+  const void* resid16; int ldr16;                 // HM_EPI_ADD_RELU: 16-bit residual (conv)
   int ksplit;                                     // HM_EPI_F32 only: K is cut into ksplit ranges, one workgroup and one [M][ldc] slab of C each
   // convolution geometry (CONV only)
   const void* zeros;
@@ -157,7 +158,8 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
       }
     if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // LDS -> row-major, bias / activation / residual, coalesced stores
-    if constexpr ((EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU || LNIN || MX8) && NCH >= 8) {
+    constexpr bool RELU = EPI == HM_EPI_RELU || EPI == HM_EPI_ADD_RELU;
+    if constexpr ((EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU || LNIN || MX8 || RELU) && NCH >= 8) {
       static_assert(!MX8 || NCH == 16, "MXFP8 output: 8 lanes per row, 4 lanes per 32-column scale block");
       // 16-bit outputs: 8 columns (two staged chunks) per lane -> one 16-byte store, NCH/2 lanes per row
       constexpr int LPR = NCH / 2, RPI2 = 64 / LPR, ITS2 = MI * 16 / RPI2;
@@ -201,6 +203,17 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
           if (ACT_GELU) { a = gelu_fast(a); b = gelu_fast(b); }
           else if (EPI == HM_EPI_SILU) { a = silu(a); b = silu(b); }
           o[q] = (elem)a; o[4 + q] = (elem)b;
+        }
+        if constexpr (RELU) {                        // (+ identity), ReLU; host guarantees N % 8 == 0 and 16-byte rows
+          typename T::vec8 idn;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) idn[q] = (elem)0.0f;
+          if (EPI == HM_EPI_ADD_RELU) idn = *(const typename T::vec8*)((const elem*)g.resid16 + (size_t)m * g.ldr16 + n);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[q] = (elem)fmaxf(__fadd_rn(v0[q], (float)idn[q]), 0.f);
+            o[4 + q] = (elem)fmaxf(__fadd_rn(v1[q], (float)idn[4 + q]), 0.f);
+          }
         }
         if (n + 8 <= g.N && (g.ldc & 7) == 0) {
           *(typename T::vec8*)((elem*)g.C + (size_t)m * g.ldc + n) = o;
@@ -270,6 +283,14 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         } else if (EPI == HM_EPI_SILU) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+        } else if (RELU) {
+          if (EPI == HM_EPI_ADD_RELU) {
+            const typename T::vec4 idn = *(const typename T::vec4*)((const elem*)g.resid16 + (size_t)m * g.ldr16 + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = __fadd_rn(v[q], (float)idn[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
         if (RES) {
           *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v + r;
@@ -863,6 +884,8 @@ int launch_conv(const KArgs& g, int epilogue, hipStream_t s) {
     case HM_EPI_STORE: return launch_conv_ni<T, HM_EPI_STORE>(g, s);
     case HM_EPI_SILU: return launch_conv_ni<T, HM_EPI_SILU>(g, s);
     case HM_EPI_F32: return launch_conv_ni<T, HM_EPI_F32>(g, s);
+    case HM_EPI_RELU: return launch_conv_ni<T, HM_EPI_RELU>(g, s);
+    case HM_EPI_ADD_RELU: return launch_conv_ni<T, HM_EPI_ADD_RELU>(g, s);
     default: return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unsupported epilogue");
   }
 }
@@ -966,8 +989,10 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   const hm_conv_args& c = *a;
   if (!c.X || !c.W || !c.Y || !c.zeros) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: null operand");
   if (c.N <= 0 || c.H <= 0 || c.W_in <= 0 || c.Cin <= 0 || c.Cout <= 0) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: empty problem");
-  if ((c.ksize != 1 && c.ksize != 3) || (c.stride != 1 && c.stride != 2))
-    return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: kernel size 1 or 3, stride 1 or 2");
+  if ((c.ksize != 1 && c.ksize != 3 && c.ksize != 5 && c.ksize != 7) || (c.stride != 1 && c.stride != 2))
+    return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: kernel size 1, 3, 5 or 7, stride 1 or 2");
+  if (c.act < 0 || c.act > 2 || (c.resid && (c.act != 2 || c.ldr % 8 != 0 || c.ldr < c.Cout || c.Cout % 8 != 0 || ((uintptr_t)c.resid & 15))))
+    return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: act is 0 / 1 (SiLU) / 2 (ReLU); resid needs act == 2, Cout % 8 == 0, ldr % 8 == 0, 16-byte alignment");
   int lg = 0;
   while ((1 << lg) < c.Cin) ++lg;
   if ((1 << lg) != c.Cin || c.Cin < 8) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: Cin must be a power of two >= 8");
@@ -985,7 +1010,8 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   k.zeros = c.zeros; k.H = c.H; k.Wd = c.W_in; k.Hout = Hout; k.Wout = Wout; k.ksz = c.ksize; k.stride = c.stride; k.pad = pad;
   k.cin_log2 = lg; k.taps = taps; k.group_m = g_group_m;
   if (c.out_f32 && c.act) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: f32 output has no activation");
-  const int epi = c.out_f32 ? HM_EPI_F32 : (c.act ? HM_EPI_SILU : HM_EPI_STORE);
+  k.resid16 = c.resid; k.ldr16 = c.ldr;
+  const int epi = c.out_f32 ? HM_EPI_F32 : (c.act == 1 ? HM_EPI_SILU : (c.act == 2 ? (c.resid ? HM_EPI_ADD_RELU : HM_EPI_RELU) : HM_EPI_STORE));
   HmProfScope prof(HM_K_CONV, c.ksize * 10 + c.stride, k.M, k.N, ktrue, stream);
   if (c.dtype == HM_DTYPE_BF16) return launch_conv<TBf16>(k, epi, stream);
   if (c.dtype == HM_DTYPE_F16) return launch_conv<TF16>(k, epi, stream);

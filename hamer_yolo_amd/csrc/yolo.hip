@@ -254,6 +254,63 @@ extern "C" int hm_maxpool_nhwc(const void* x, int ldx, void* y, int ldy, int N, 
   return rc != HM_OK ? rc : hm_check_launch("hm_maxpool_nhwc");
 }
 
+template <class E>
+__global__ __launch_bounds__(256) void nchw3_to_nhwc8_kernel(const float* __restrict__ x, E* __restrict__ y, int B, int HW) {
+  typedef __attribute__((ext_vector_type(8))) E vec8;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)B * HW) return;
+  const size_t b = gid / HW, p = gid % HW;
+  const float* xb = x + b * 3 * (size_t)HW + p;
+  vec8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (E)0.0f;
+  o[0] = (E)xb[0]; o[1] = (E)xb[HW]; o[2] = (E)xb[2 * (size_t)HW];
+  *(vec8*)(y + gid * 8) = o;
+}
+
+// one workgroup per image: channel sums over HW (coalesced over channels), dot with w, + bias, * k
+template <class E>
+__global__ __launch_bounds__(256) void gap_linear_kernel(const E* __restrict__ feat, int HW, int C, const float* __restrict__ w,
+                                                         float bias, const float* __restrict__ kv, float* __restrict__ depth) {
+  __shared__ float part[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const E* f = feat + (size_t)b * HW * C;
+  float acc = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += (float)f[(size_t)p * C + c];
+    acc = fmaf(s / (float)HW, w[c], acc);
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) part[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) depth[b] = ((part[0] + part[1]) + (part[2] + part[3]) + bias) * kv[b];
+}
+
+extern "C" int hm_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, int dtype, void* stream_) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || ((uintptr_t)y & 15)) return hm_set_error(HM_ERR_ARG, "hm_nchw3_to_nhwc8: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  const size_t total = (size_t)B * H * W;
+  const int rc = with_dtype(dtype, [&](auto* tag) {
+    using E = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(nchw3_to_nhwc8_kernel<E>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, (E*)y, B, H * W);
+    return HM_OK;
+  });
+  return rc != HM_OK ? rc : hm_check_launch("hm_nchw3_to_nhwc8");
+}
+
+extern "C" int hm_gap_linear(const void* feat, int HW, int C, const float* w, float bias, const float* k_value, float* depth, int B,
+                             int dtype, void* stream_) {
+  if (!feat || !w || !k_value || !depth || HW <= 0 || C <= 0 || B <= 0) return hm_set_error(HM_ERR_ARG, "hm_gap_linear: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  const int rc = with_dtype(dtype, [&](auto* tag) {
+    using E = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(gap_linear_kernel<E>, dim3(B), dim3(256), 0, s, (const E*)feat, HW, C, w, bias, k_value, depth);
+    return HM_OK;
+  });
+  return rc != HM_OK ? rc : hm_check_launch("hm_gap_linear");
+}
+
 extern "C" int hm_upsample2x_nhwc(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream_) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return hm_set_error(HM_ERR_ARG, "hm_upsample2x_nhwc: bad arguments");
   if (C % 8 || ldx % 8 || ldy % 8 || (((uintptr_t)x | (uintptr_t)y) & 15)) return hm_set_error(HM_ERR_ARG, "hm_upsample2x_nhwc: C, ld % 8 and 16-byte alignment");

@@ -1,6 +1,72 @@
-"""``d_infer.py`` of the reference is ``infer.py`` plus a root depth fed to the camera maths as
-``depth_refine`` (d_infer.py:355,:438-440,:1275-1277 -> renderer.py:47-52).  ``estimate_from_rgb``
-here already takes ``depth_refine``; the RootNet regressor that produces the depth is listed as
-"next" in SURVEY.md 8(f) and is not part of this build yet, so the caller supplies the depth."""
+"""``d_infer.py`` of the reference is ``infer.py`` plus a root depth from RootNet fed to the camera maths as
+``depth_refine`` (reference: hamer/d_infer.py:21,:355,:438-440,:1223-1318 -> renderer.py:47-52): per detected hand
+``depth = sar.estimate_root_depth_custom(image, k_real, bbox)`` then ``estimate_from_rgb(image, [bbox], k_real,
+depth_refine=depth)``.  Everything else (``hamer_inference``, savers, CLI) is infer.py's."""
+import argparse
+import os
+
+import numpy as np
+
 from .infer import *  # noqa: F401,F403
-from .infer import hamer_inference  # noqa: F401
+from .infer import (_detection_list, _imread_bgr, _list_images, hamer_inference, hamer_opt, hand_record, load_intrinsics,  # noqa: F401
+                    reconstruct_and_save_obj_with_wrapper)
+from .rootnet.Model_RGB import get_model  # noqa: F401
+
+
+def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None, detector=None, sar=None):
+    """d_infer.py:1223-1318: as infer.py's, with the RootNet depth per hand.  ``k_real`` is required here (the depth is
+    metric only with real intrinsics; the reference passes its camera file).  One RootNet and one HaMeR forward per hand, as in
+    the reference (each hand's camera translation uses its own depth)."""
+    os.makedirs(output_folder, exist_ok=True)
+    if k_real is None:
+        raise ValueError("d_infer needs camera intrinsics (k_real)")
+    if hamer is None:
+        hamer = hamer_inference(hamer_opt)
+    if detector is None:
+        from .config.yolo_config import yolo_opt
+        from .yolo.detector import Detector
+        detector = Detector(yolo_opt)
+    if sar is None:
+        sar = get_model()
+    for img_path in _list_images(input_folder):
+        file_name = os.path.splitext(os.path.basename(img_path))[0]
+        image_results = {'left': None, 'right': None}
+        try:
+            image = _imread_bgr(img_path)
+            if image is None:
+                continue
+            _, dets = detector.detect(image)
+            detection_list = _detection_list(dets)
+            if not detection_list:
+                continue
+            for bbox in detection_list:
+                try:
+                    depth_pred = sar.estimate_root_depth_custom(image, k_real, bbox[1])
+                    output, _ = hamer.estimate_from_rgb(image, [bbox], k_real, depth_refine=depth_pred)
+                    image_results[bbox[0]] = hand_record(output, bbox[0] == 'right', 0)
+                except Exception as e:
+                    print(f"Error processing hand in {file_name}: {e}")
+                    continue
+            np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
+        except Exception as e:
+            print(f"Error processing file {img_path}: {e}")
+            continue
+
+
+def main(argv=None):
+    """``python -m hamer_yolo_amd.d_infer --input <RGB_dir> --output <out_dir> --intrinsics <cam_K.txt>``."""
+    ap = argparse.ArgumentParser(description="YOLOv7 -> RootNet depth + HaMeR -> MANO parameters (.npy per image)")
+    ap.add_argument('--input', type=str, required=True)
+    ap.add_argument('--output', type=str, required=True)
+    ap.add_argument('--intrinsics', type=str, required=True, help="3x3 camera matrix txt")
+    ap.add_argument('--obj', type=str, default=None, help="also reconstruct OBJ meshes into this folder")
+    args = ap.parse_args(argv)
+    k_real = load_intrinsics(args.intrinsics)
+    hamer = hamer_inference(hamer_opt)
+    process_batch_manopara(args.input, args.output, k_real, hamer=hamer)
+    if args.obj:
+        reconstruct_and_save_obj_with_wrapper(args.output, args.obj, hamer)
+
+
+if __name__ == '__main__':
+    main()

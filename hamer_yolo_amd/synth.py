@@ -333,3 +333,32 @@ def frame_u8(h: int = 1080, w: int = 1920, seed: int = 0, smooth: int = 8) -> to
     img = (c00 * (s - fy) * (s - fx) + c01 * (s - fy) * fx + c10 * fy * (s - fx) + c11 * fy * fx) // (s * s)
     fine = (_hash_u32(torch.arange(h * w * 3, dtype=torch.int64), name_seed("frame.fine", seed)) >> 27).reshape(h, w, 3) - 16
     return (img + fine).clamp(0, 255).to(torch.uint8).contiguous()
+
+
+def rootnet_state_dict(seed: int = 0):
+    """Seeded random-init weights with the reference's RootNet checkpoint keys: ``net`` = the SAR state dict's backbone part
+    (``backbone.extract_mid.*`` / ``backbone.extract_high.0.*``, torchvision resnet34 wrapped as in rootnet/Model_RGB.py:179-196)
+    and ``rootnet`` = ``depth_layer.{weight,bias}`` (:253-259).  He-style widths keep the ReLU activations O(1) through the
+    16 residual blocks; the residual branch's second BatchNorm is scaled down as zero-init-residual training does."""
+    from .rootnet import arch
+    net: Dict[str, torch.Tensor] = {}
+
+    def conv(key, co, ci, k):
+        net[key + ".weight"] = uniform(key + ".weight", (co, ci, k, k), (6.0 / (ci * k * k)) ** 0.5, 0.0, seed=seed)
+
+    def bn(key, c, gain=1.0):
+        net[key + ".weight"] = uniform(key + ".weight", (c,), 0.1 * gain, gain, seed=seed)
+        net[key + ".bias"] = uniform(key + ".bias", (c,), 0.1, 0.0, seed=seed)
+        net[key + ".running_mean"] = uniform(key + ".running_mean", (c,), 0.1, 0.0, seed=seed)
+        net[key + ".running_var"] = uniform(key + ".running_var", (c,), 0.2, 1.0, seed=seed)
+
+    conv(arch.STEM_CONV, 64, 3, 7)
+    bn(arch.STEM_BN, 64)
+    for pre, cin, cout, s, ds in arch.blocks():
+        conv(pre + "conv1", cout, cin, 3); bn(pre + "bn1", cout)
+        conv(pre + "conv2", cout, cout, 3); bn(pre + "bn2", cout, gain=0.5)
+        if ds:
+            conv(pre + "downsample.0", cout, cin, 1); bn(pre + "downsample.1", cout)
+    root = {"depth_layer.weight": uniform("depth_layer.weight", (1, 512, 1, 1), 0.05, 0.02, seed=seed),
+            "depth_layer.bias": uniform("depth_layer.bias", (1,), 0.05, 0.3, seed=seed)}
+    return net, root

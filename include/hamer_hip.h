@@ -41,7 +41,9 @@ enum {
   HM_EPI_RESID_LN = 5,  /* RESID_F32, plus ln_xg = C*ln_gamma (16-bit) and ln_stats     */
   HM_EPI_LN_STORE = 6,  /* C(16-bit) = rstd*(acc - mean*ln_colsum) + bias               */
   HM_EPI_LN_GELU = 7,   /* C(16-bit) = gelu_erf(rstd*(acc - mean*ln_colsum) + bias)     */
-  HM_EPI_GELU_MX8 = 8   /* hm_gemm_fp8 only: C = MXFP8(gelu_erf(acc + bias)): e4m3 bytes + E8M0 scale per 32 columns */
+  HM_EPI_GELU_MX8 = 8,  /* hm_gemm_fp8 only: C = MXFP8(gelu_erf(acc + bias)): e4m3 bytes + E8M0 scale per 32 columns */
+  HM_EPI_RELU = 9,      /* hm_conv2d_nhwc only: C(16-bit) = relu(acc + bias)                 torchvision BasicBlock     */
+  HM_EPI_ADD_RELU = 10  /* hm_conv2d_nhwc only: C(16-bit) = relu(acc + bias + resid16[m][n]) (out += identity; relu)    */
 };
 
 typedef struct hm_gemm_args {
@@ -263,12 +265,14 @@ typedef struct hm_conv_args {
   const float* bias;  /* [Cout]                                                                        */
   const void* zeros;  /* >= 16 zero bytes on the device: source of padding taps                        */
   int N, H, W_in, Cin, Cout, ksize, stride, ldx, ldy, Kpad;
-  int act;            /* 1: SiLU (Conv.fuseforward, common.py:114)                                     */
+  int act;            /* 1: SiLU (Conv.fuseforward, common.py:114); 2: ReLU (ResNet-34 of the RootNet backbone) */
   int out_f32;        /* 1: f32 output, no activation (detect head, yolo.py:151)                       */
   int dtype;
+  const void* resid;  /* optional with act == 2: [N][Hout][Wout][ldr] 16-bit added before the ReLU (BasicBlock identity) */
+  int ldr;
 } hm_conv_args;
 
-/* Conv2d(k in {1,3}, stride in {1,2}, pad k/2) + bias (+ SiLU) as an implicit GEMM on MFMA.
+/* Conv2d(k in {1,3,5,7}, stride in {1,2}, pad k/2) + bias (+ SiLU / ReLU / residual add + ReLU) as an implicit GEMM on MFMA.
  * Cin must be a power of two >= 8 (the 3-channel image is stored with 8 channels). */
 int hm_conv2d_nhwc(const hm_conv_args* args, void* stream);
 
@@ -276,6 +280,14 @@ int hm_conv2d_nhwc(const hm_conv_args* args, void* stream);
  * k=5/9/13, s=1, pad k/2 -- the 9 and 13 windows are cascades of the 5 window). C % 8 == 0. */
 int hm_maxpool_nhwc(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int k, int stride, int pad,
                     int dtype, void* stream);
+
+/* (B,3,H,W) f32 planes -> NHWC 16-bit with 8 channels (3 real, 5 zero): the convolution input layout, for crops that
+ * hm_crop_batch produced in HaMeR's layout (RootNet patch, rootnet/Model_RGB.py:596-610). */
+int hm_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, int dtype, void* stream);
+/* ResRootNet.forward_coord (rootnet/Model_RGB.py:282-292): global average pool of feat [B][HW][C] (16-bit), 1x1 conv to
+ * one channel (w [C], bias), times k_value[b] -> depth [B] f32. */
+int hm_gap_linear(const void* feat, int HW, int C, const float* w, float bias, const float* k_value, float* depth, int B,
+                  int dtype, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode='nearest') on NHWC 16-bit (yolov7.yaml:78,:92). C % 8 == 0. */
 int hm_upsample2x_nhwc(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int dtype, void* stream);

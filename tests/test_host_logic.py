@@ -246,3 +246,19 @@ def test_lightning_checkpoint_with_foreign_objects(tmp_path):
         del sys.modules["yacs_like.config"], sys.modules["yacs_like"]
     out = _read_state_dict(path)
     assert out.keys() == sd.keys() and all(torch.equal(out[k], sd[k]) for k in sd)
+
+
+def test_rootnet_bbox_and_k_known_answers():
+    """process_bbox (rootnet/preprocessing.py:166-188) and calculate_k (Model_RGB.py:494-498): product mirror and oracle
+    against hand-derived values.  Box 100x60 at (200, 150) in a 640x480 image: sanitize shrinks w, h by one (x2 = x1 + w - 1),
+    the square side is max(w, h) * 1.5."""
+    import numpy as np
+    from hamer_yolo_amd.rootnet.preprocessing import process_bbox, sanitize_bbox
+    from oracle import rootnet_ref as RR
+    b = process_bbox([200.0, 150.0, 100.0, 60.0], 640, 480, (256, 256), 1.5)
+    np.testing.assert_allclose(b, [200 + 49.5 - 74.25, 150 + 29.5 - 74.25, 148.5, 148.5], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(RR.process_bbox([200.0, 150.0, 100.0, 60.0], 640, 480, (256, 256), 1.5), b, atol=1e-4)
+    assert sanitize_bbox([10.0, 10.0, 0.0, 50.0], 640, 480) is None and RR.sanitize_bbox([10.0, 10.0, 0.0, 50.0], 640, 480) is None
+    np.testing.assert_allclose(sanitize_bbox([-20.0, 400.0, 100.0, 200.0], 640, 480), [0, 400, 99, 79])
+    # k = sqrt(0.3 * 0.3 * fx * fy / (w * h)): fx = fy = 1000, 150 px square -> 0.3 * 1000 / 150 = 2
+    assert abs(RR.calculate_k([0, 0, 150.0, 150.0], 1000.0, 1000.0) - 2.0) < 1e-6
