@@ -14,7 +14,9 @@ n = eng.lib.hm_hamer_workspace_bytes(__import__("ctypes").byref(eng.w), B)
 NS = 4
 wss = [torch.empty(n, dtype=torch.uint8, device="cuda") for _ in range(NS)]
 outs = [eng.alloc_outputs(B) for _ in range(NS)]
-streams = [torch.cuda.Stream() for _ in range(NS)]
+import os
+PRI = os.environ.get("PRI", "0") == "1"
+streams = [torch.cuda.Stream(priority=(-1 if (PRI and i % 2 == 0) else 0)) for i in range(NS)]
 def run(nstreams, steps=40):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
