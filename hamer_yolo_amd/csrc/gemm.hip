@@ -847,7 +847,8 @@ int pick_variant(const KArgs& g) {
   }
   if (g_variant >= 0) return g_variant;
   if (g.M < 1024 || g.N < 512) return 0;
-  return g.K >= 2560 ? 9 : 10;     // (variant 24, X two K-steps ahead: -2 % per GEMM in isolation, nothing over a whole step)
+  return 24;     // X two K-steps ahead (gemm_x3_kernel) for the store / gelu / residual epilogues, else the variant-10 tile:
+                 // -2 % per GEMM in isolation, +0.5 % hands/s with two batches in flight
 }
 
 template <class T>
