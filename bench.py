@@ -278,7 +278,7 @@ def main():
             t = json.load(open(traffic_src))
             w = {"patch": 1, "qkv": cfg.vit.depth, "proj": cfg.vit.depth, "fc1": cfg.vit.depth, "fc2": cfg.vit.depth, "kv": 1}
             traffic = round(sum(t[k]["hbm_bytes"] * n for k, n in w.items()) / sum(w.values()))
-        kernel_name, peak = "gemm_tn_kernel (all epilogues)", PEAK_BF16_TFLOPS
+        kernel_name, peak = "gemm_x3_kernel / gemm_tn_kernel (the 256x256 MFMA GEMM, all epilogues)", PEAK_BF16_TFLOPS
         if args.dtype == "fp8":      # dominant kernel = gemm_fp8_kernel: price its launches against the fp8 peak
             f8 = [(M_, N_, K_, ms_) for (kd, e_, M_, N_, K_, ms_) in prof.records if kd == "gemm" and e_ >= 16]
             achieved = sum(2.0 * a * b * c for a, b, c, _ in f8) / (sum(t for *_, t in f8) * 1e-3) / 1e12

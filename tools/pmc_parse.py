@@ -12,7 +12,7 @@ from pmc_shapes import SHAPES, M  # noqa: E402
 def per_kernel(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ours = [r for r in rows if any(k in r["Kernel_Name"] for k in ("gemm_tn_kernel", "gemm_pipe_kernel", "layernorm_kernel", "vit_attention_kernel"))]
+    ours = [r for r in rows if any(k in r["Kernel_Name"] for k in ("gemm_tn_kernel", "gemm_x3_kernel", "layernorm_kernel", "vit_attention_kernel"))]
     return [float(r["Counter_Value"]) for r in ours]
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
