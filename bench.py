@@ -161,7 +161,6 @@ def main():
                     help="crops: BASELINE configs[1] (default, the contract line); e2e: configs[2], 1080p frames through "
                          "YOLOv7 + crop + HaMeR with 4 fixed boxes per frame (not a contract line, for DESIGN.md)")
     ap.add_argument("--frames", type=int, default=16, help="e2e: frames per step (hands per step = 4 x frames)")
-    ap.add_argument("--split", type=int, default=-1, help="1/0: force the two-stream half-batch schedule on/off (default: engine's choice)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: consecutive steps alternate between this many HIP streams (own workspace and outputs "
                          "each), so one batch's HBM-bound phases overlap another's MFMA phases; 1 = strictly one after the other; "
@@ -203,14 +202,13 @@ def main():
     ctxs = eng.contexts(B, args.in_flight if args.in_flight > 0 else 2)
     torch.cuda.synchronize()
 
-    split = None if args.split < 0 else bool(args.split)
     nstep = [0]
 
     def step():
         c = ctxs[nstep[0] % len(ctxs)]                   # every step is one whole batch; steps alternate between the contexts
         nstep[0] += 1
         with torch.cuda.stream(c.stream):
-            eng.forward(img, c.out, split=split, workspace=c.workspace)
+            eng.forward(img, c.out, workspace=c.workspace)
             if world > 1:
                 shard.gather_mano(shard.pack_mano(c.out), dst=0)
 
@@ -259,7 +257,7 @@ def main():
         nprof = min(args.steps, 5)
         with L.profile(capacity=nprof * 512) as prof:
             for _ in range(nprof):
-                eng.forward(img, out, split=False)      # one stream: every launch timed alone, nothing overlapping it
+                eng.forward(img, out)                   # one stream: every launch timed alone, nothing overlapping it
             torch.cuda.synchronize()
         by_kind, gemm_fl, gemm_ms, per = {}, 0.0, 0.0, {}
         for kind, epi, M, N, K, ms in prof.records:

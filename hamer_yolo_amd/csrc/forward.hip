@@ -73,15 +73,13 @@ int check_weights(const hm_hamer_weights* w) {
 
 extern "C" size_t hm_hamer_workspace_bytes(const hm_hamer_weights* w, int B) {
   if (!w || B <= 0) return 0;
-  const size_t whole = make_layout(*w, B).total;
-  const size_t halves = B > 1 ? make_layout(*w, (B + 1) / 2).total + make_layout(*w, B / 2).total : 0;   // hm_hamer_forward_split
-  return whole > halves ? whole : halves;
+  return make_layout(*w, B).total;
 }
 
 #define HM_TRY(expr) do { int _rc = (expr); if (_rc != HM_OK) return _rc; } while (0)
 
-static int forward_impl(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out, void* workspace,
-                        size_t workspace_bytes, void* stream, hipEvent_t after_first_block) {
+extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   HM_TRY(check_weights(w));
   if (!img || !out || !workspace || B <= 0) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: bad arguments");
   if (!out->pose6d || !out->betas || !out->cam || !out->rotmats || !out->verts || !out->joints || !out->cam_t || !out->kp2d)
@@ -188,8 +186,6 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
       HM_TRY(resid_gemm_ln(mlp, w->mlp_dim, b.fc2_w, b.fc2_b, L.ksplit_fc2, last ? w->last_g : w->blocks[i + 1].ln1_g,
                            last ? w->last_b : w->blocks[i + 1].ln1_b, last ? tok : h));
     }
-    if (i == 0 && after_first_block && hipEventRecord(after_first_block, (hipStream_t)stream) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "hm_hamer_forward_split: hipEventRecord failed");
   }
   if (fold || fp8) HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
 
@@ -224,37 +220,3 @@ static int forward_impl(const hm_hamer_weights* w, const float* img, int B, cons
                          out->kp2d, B, w->focal_length, w->image_size, stream);
 }
 
-extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
-                                void* workspace, size_t workspace_bytes, void* stream) {
-  return forward_impl(w, img, B, out, workspace, workspace_bytes, stream, nullptr);
-}
-
-// Two half-batches on two streams, the second one ViT block behind the first, so that the GEMM epilogues
-// (HBM write bursts: every CU stores its 256x256 tile at the same moment), the HBM-bound LayerNorms and the
-// partially filled last round of tiles of one half overlap the fill-bound K loops of the other.  Crops are
-// independent, so the outputs are bit-identical to hm_hamer_forward.  Events and the second stream are the
-// caller's; on return `stream` has been made to wait for everything enqueued on `stream2`.
-extern "C" int hm_hamer_forward_split(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
-                                      void* workspace, size_t workspace_bytes, void* stream, void* stream2,
-                                      void* ev_fork, void* ev_join) {
-  if (B < 2 || !stream2 || !ev_fork || !ev_join) return forward_impl(w, img, B, out, workspace, workspace_bytes, stream, nullptr);
-  HM_TRY(check_weights(w));
-  if (!img || !out || !workspace) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward_split: bad arguments");
-  const int B0 = (B + 1) / 2, B1 = B / 2;
-  const size_t ws0 = make_layout(*w, B0).total, ws1 = make_layout(*w, B1).total;
-  if (workspace_bytes < ws0 + ws1) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward_split: workspace too small");
-  const int gh = (w->img_h + 2 * w->pad - w->patch) / w->patch + 1, gw = (w->win_w + 2 * w->pad - w->patch) / w->patch + 1;
-  const int V = w->mano.n_verts;
-  hm_hamer_outputs o1 = *out;
-  o1.pose6d += (size_t)B0 * 96; o1.betas += (size_t)B0 * 10; o1.cam += (size_t)B0 * 3; o1.rotmats += (size_t)B0 * 144;
-  o1.verts += (size_t)B0 * V * 3; o1.joints += (size_t)B0 * 63; o1.cam_t += (size_t)B0 * 3; o1.kp2d += (size_t)B0 * 42;
-  if (o1.tokens) o1.tokens = (char*)o1.tokens + (size_t)B0 * gh * gw * w->embed_dim * 2;
-  const float* img1 = img + (size_t)B0 * 3 * w->img_h * w->img_w_full;
-  hipStream_t s0 = (hipStream_t)stream, s1 = (hipStream_t)stream2;
-  HM_TRY(forward_impl(w, img, B0, out, workspace, ws0, stream, (hipEvent_t)ev_fork));
-  if (hipStreamWaitEvent(s1, (hipEvent_t)ev_fork, 0) != hipSuccess) return hm_set_error(HM_ERR_HIP, "hm_hamer_forward_split: hipStreamWaitEvent failed");
-  HM_TRY(forward_impl(w, img1, B1, &o1, (char*)workspace + ws0, ws1, stream2, nullptr));
-  if (hipEventRecord((hipEvent_t)ev_join, s1) != hipSuccess || hipStreamWaitEvent(s0, (hipEvent_t)ev_join, 0) != hipSuccess)
-    return hm_set_error(HM_ERR_HIP, "hm_hamer_forward_split: join failed");
-  return HM_OK;
-}

@@ -38,8 +38,6 @@ class HamerEngine:
         self.device = torch.device(device)
         self.dtype = dtype
         self._keep = []          # device tensors referenced by raw pointers
-        self._stream2 = None     # second stream + events of forward(split=True), created on first use
-        self.split = os.environ.get("HAMER_SPLIT", "0") == "1"    # measured 2.5 % slower at B=64: off
         self._ws = None
         self._ws_B = 0
         v, d = self.cfg.vit, self.cfg.dec
@@ -196,10 +194,8 @@ class HamerEngine:
         return o
 
     def forward(self, img: torch.Tensor, out: Optional[Dict[str, torch.Tensor]] = None,
-                want_tokens: bool = False, split: Optional[bool] = None,
-                workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """img: (B, 3, 256, 256) fp32 normalised crops on the device.  split (default off; HAMER_SPLIT=1): run the two
-        halves of the batch on two HIP streams, one ViT block apart (hm_hamer_forward_split; same results)."""
+                want_tokens: bool = False, workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """img: (B, 3, 256, 256) fp32 normalised crops on the device; one hm_hamer_forward enqueue on the current stream."""
         if not img.is_cuda:
             raise L.HipLibraryError("HamerEngine.forward takes a device tensor")
         B = img.shape[0]
@@ -211,18 +207,6 @@ class HamerEngine:
         ho = L.HamerOutputs(L.ptr(out["pose6d"]), L.ptr(out["betas"]), L.ptr(out["pred_cam"]), L.ptr(out["rotmats"]),
                             L.ptr(out["pred_vertices"]), L.ptr(out["pred_keypoints_3d"]), L.ptr(out["pred_cam_t"]),
                             L.ptr(out["pred_keypoints_2d"]), L.ptr(out.get("tokens")))
-        if split is None:
-            split = self.split and B >= 16
-        if split:
-            if self._stream2 is None:
-                self._stream2 = (torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event())
-                for ev in self._stream2[1:]:
-                    ev.record()                                   # materialise the hipEvent_t handles
-            s2, e0, e1 = self._stream2
-            L.check(self.lib.hm_hamer_forward_split(C.byref(self.w), L.ptr(img), B, C.byref(ho), L.ptr(ws), ws.numel(),
-                                                    L.current_stream(), s2.cuda_stream, e0.cuda_event, e1.cuda_event),
-                    "hm_hamer_forward_split")
-        else:
-            L.check(self.lib.hm_hamer_forward(C.byref(self.w), L.ptr(img), B, C.byref(ho), L.ptr(ws), ws.numel(),
-                                              L.current_stream()), "hm_hamer_forward")
+        L.check(self.lib.hm_hamer_forward(C.byref(self.w), L.ptr(img), B, C.byref(ho), L.ptr(ws), ws.numel(),
+                                          L.current_stream()), "hm_hamer_forward")
         return out

@@ -342,13 +342,6 @@ int hm_prof_begin(int capacity);                        /* allocate 2*capacity e
 int hm_prof_collect(hm_prof_record* out_host, int cap); /* sync, copy records, clear; returns count   */
 int hm_prof_end(void);                                  /* stop logging, destroy the events           */
 
-/* Same computation as hm_hamer_forward, issued as two half-batches on two caller-owned streams (the second
- * one ViT block behind the first) so HBM-bound phases of one half overlap MFMA phases of the other.
- * ev_fork / ev_join: caller-owned hipEvent_t.  On return `stream` waits for all work enqueued on `stream2`.
- * Workspace: hm_hamer_workspace_bytes(w, B) covers both forms.  Outputs are bit-identical to hm_hamer_forward. */
-int hm_hamer_forward_split(const hm_hamer_weights* w, const float* img, int B, const hm_hamer_outputs* out,
-                           void* workspace, size_t workspace_bytes, void* stream, void* stream2, void* ev_fork, void* ev_join);
-
 int hm_version(void);
 const char* hm_last_error_string(void);
 

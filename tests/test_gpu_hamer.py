@@ -104,27 +104,6 @@ def test_batch64_is_batch_invariant():
     np.testing.assert_allclose((r @ r.transpose(-1, -2)).cpu().numpy(), eye.cpu().numpy(), atol=1e-5)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("B", [2, 5, 16])
-def test_split_forward_is_bit_identical(B):
-    """hm_hamer_forward_split (two half-batches on two streams) == hm_hamer_forward, bit for bit, odd batches too."""
-    import torch
-    from hamer_yolo_amd import synth
-    from hamer_yolo_amd.engine import HamerEngine
-    cfg = synth.tiny_config()
-    sd = synth.hamer_state_dict(cfg, seed=3, device="cuda", bf16_representable=True)
-    eng = HamerEngine(sd, synth.mano_params(seed=3), cfg)
-    img = synth.normalize_crops(synth.crops_u8(B, seed0=40)).cuda()
-    a = eng.forward(img, want_tokens=True, split=False)
-    torch.cuda.synchronize()
-    a = {k: v.clone() for k, v in a.items()}
-    for _ in range(3):
-        b = eng.forward(img, want_tokens=True, split=True)
-    torch.cuda.synchronize()
-    for k in a:
-        assert torch.equal(a[k], b[k]), k
-
-
 def test_batches_in_flight_do_not_interfere():
     """HamerEngine.contexts: four different batches issued back to back on two contexts (own stream, workspace, outputs)
     give, each, bit for bit what a lone forward gives."""
