@@ -4,8 +4,9 @@ ResRootNet, :494-498 calculate_k, :572-639 estimate_root_depth_custom; rootnet/p
 TEST INFRASTRUCTURE ONLY.  The backbone is torchvision's resnet34, which is not installed in this image and not part of
 the reference tree: its published architecture (stem 7x7/2 - bn - relu - maxpool 3x3/2; BasicBlocks [3, 4, 6, 3] of
 conv3x3-bn-relu-conv3x3-bn + identity / (conv1x1-bn)(x), relu; eval-mode BatchNorm eps 1e-5) is restated with
-torch.nn.functional on the checkpoint's own state-dict keys.  PARITY UNPINNED against torchvision itself; process_bbox and
-calculate_k are pinned by known answers, the patch by oracle/crop_ref.py (same affine and cv2 restatement as HaMeR's crop).
+torch.nn.functional on the checkpoint's own state-dict keys.  PARITY UNPINNED against torchvision itself for the backbone;
+ResRootNet.forward, process_bbox and calculate_k are pinned against the reference's own code (tests/golden/rootnet_head.npz,
+tools/gen_golden_rootnet.py), the patch by oracle/crop_ref.py (same affine and cv2 restatement as HaMeR's crop).
 """
 import numpy as np
 import torch

@@ -58,3 +58,29 @@ def test_mano_rest_pose_is_template():
     eye = torch.eye(3).expand(2, 16, 3, 3).contiguous()
     verts, joints = R.mano_forward(mp, torch.zeros(2, 10), eye)
     np.testing.assert_allclose(verts.numpy(), mp["v_template"][None].expand(2, -1, -1).numpy(), atol=1e-6)
+
+
+def test_rootnet_head_bbox_and_k_match_reference(golden_dir):
+    """ResRootNet.forward, process_bbox and calculate_k of the reference (captured by tools/gen_golden_rootnet.py) against the
+    oracle restatement and against the product's host mirror (hamer_yolo_amd/rootnet/preprocessing.py)."""
+    import os
+    import numpy as np
+    import torch
+    from hamer_yolo_amd.rootnet.preprocessing import process_bbox
+    from oracle import rootnet_ref as RR
+    g = np.load(os.path.join(golden_dir, "rootnet_head.npz"))
+    W, H = int(g["img_wh"][0]), int(g["img_wh"][1])
+    ks = []
+    for b, want in zip(g["boxes"], g["processed"]):
+        got_o = RR.process_bbox(list(b), W, H, (256, 256), 1.5)
+        got_p = process_bbox(b.copy(), W, H, (256, 256), 1.5)
+        if np.isnan(want[0]):
+            assert got_o is None and got_p is None
+            continue
+        np.testing.assert_allclose(got_o, want, rtol=0, atol=1e-4)
+        np.testing.assert_array_equal(got_p, want)            # the mirror keeps the reference's exact arithmetic
+        ks.append(RR.calculate_k(want, float(g["fx_fy"][0]), float(g["fx_fy"][1])))
+    np.testing.assert_allclose(ks, g["k_of_processed"], rtol=1e-6)
+    root = {"depth_layer.weight": torch.from_numpy(g["depth_w"]), "depth_layer.bias": torch.from_numpy(g["depth_b"])}
+    d = RR.root_depth(root, torch.from_numpy(g["feats"]), torch.from_numpy(g["k_value"]))
+    np.testing.assert_allclose(d.numpy(), g["depth"], rtol=1e-5, atol=1e-7)
