@@ -19,7 +19,7 @@ struct Layout {
 // proj / fc2 at 4 hands: 60 tiles x 20 / 80 K-steps on 60 CUs -> 240 workgroups x 5 / 20 K-steps.
 int pick_split_k(int M, int N, int K) {
   const int tiles = ((M + 127) / 128) * ((N + 127) / 128), nk = K / 64;
-  if (M >= 1024 || N < 512 || K % 64 != 0 || tiles * 2 > 256) return 1;     // M < 1024: hm_gemm's 128x128 tile
+  if (M > 2048 || N < 512 || K % 64 != 0 || tiles * 2 > 256) return 1;      // few hands: hm_gemm picks its 128x128 tile there
   int want = 256 / tiles;
   if (want > 8) want = 8;                               // the consumer reads every slab: diminishing returns
   if (want > nk) want = nk;

@@ -847,6 +847,10 @@ int pick_variant(const KArgs& g) {
   }
   if (g_variant >= 0) return g_variant;
   if (g.M < 1024 || g.N < 512) return 0;
+  // the 256x256 tile only when its tiles fill whole rounds of the 256 CUs: at 16-32 hands proj / fc2 have 60-120 of them
+  // and qkv 180-360, and the 128x128 tile (2 workgroups per CU) is 20-60 % faster over the forward
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), rounds = (tiles + 255) / 256;
+  if (tiles * 100 < rounds * 256 * 85) return 0;
   return 24;     // X two K-steps ahead (gemm_x3_kernel) for the store / gelu / residual epilogues, else the variant-10 tile:
                  // -2 % per GEMM in isolation, +0.5 % hands/s with two batches in flight
 }

@@ -83,22 +83,25 @@ def test_vith_forward_vs_reference_golden(golden_dir, dtype, fold_ln):
 
 
 def test_batch64_is_batch_invariant():
-    """BASELINE config 2 size (B=64): per-crop results do not depend on the batch they ride in,
-    repeated crops give identical rows, and the output is finite."""
+    """BASELINE config 2 size (B=64): per-crop results do not depend on the batch they ride in -- repeated crops give
+    identical rows, a batch of 16 (other GEMM tile shapes, same summation order) gives the same numbers, a batch of 8 (split-K
+    path: other summation order, other bf16 rounding flips) stays far inside the 1e-3 parity bar -- and the output is finite."""
     cfg = synth.HamerConfig()
     sd = synth.hamer_state_dict(cfg, seed=0, device="cuda", bf16_representable=True)
     eng = HamerEngine(sd, synth.mano_params(seed=0), cfg)
-    u8 = synth.crops_u8(8, seed0=0)
-    img8 = synth.normalize_crops(u8).cuda()
-    img64 = img8.repeat(8, 1, 1, 1)
-    o8 = {k: v.clone() for k, v in eng.forward(img8).items()}
+    u8 = synth.crops_u8(16, seed0=0)
+    img16 = synth.normalize_crops(u8).cuda()
+    img64 = img16.repeat(4, 1, 1, 1)
+    o16 = {k: v.clone() for k, v in eng.forward(img16).items()}
+    o8 = {k: v.clone() for k, v in eng.forward(img16[:8].contiguous()).items()}
     o64 = eng.forward(img64)
     torch.cuda.synchronize()
     for k in ("pose6d", "betas", "pred_cam", "pred_vertices", "pred_keypoints_3d"):
-        a, b = o8[k], o64[k]
+        a, b = o16[k], o64[k]
         assert torch.isfinite(b).all()
-        assert torch.equal(b[:8], b[56:64]), k
-        np.testing.assert_allclose(b[:8].cpu().numpy(), a.cpu().numpy(), atol=1e-6, rtol=0)
+        assert torch.equal(b[:16], b[48:64]), k
+        np.testing.assert_allclose(b[:16].cpu().numpy(), a.cpu().numpy(), atol=1e-6, rtol=0)
+        np.testing.assert_allclose(o8[k].cpu().numpy(), b[:8].cpu().numpy(), atol=5e-4, rtol=0)
     r = o64["rotmats"]
     eye = torch.eye(3, device="cuda").expand_as(r)
     np.testing.assert_allclose((r @ r.transpose(-1, -2)).cpu().numpy(), eye.cpu().numpy(), atol=1e-5)
