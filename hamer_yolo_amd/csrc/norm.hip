@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256, 8) void layernorm_kernel(const float* __restri
       const int i = lane * 4 + j * 256;
       a[j] = (bias && i < D) ? *(const f32x4_t*)(bias + i) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll 2
-    for (int s = 0; s < n_part; ++s) {             // slab by slab: the MAXJ loads of a slab are in flight together
+#pragma unroll 4
+    for (int s = 0; s < n_part; ++s) {             // slab by slab, four slabs (4 x MAXJ loads) in flight together
       const float* pr = part + ((size_t)s * M + row) * D;
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
