@@ -715,8 +715,13 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const KArgs g) {
   dma_w(0, 0);
   if (nk > 1) dma_x(1, 1);
   float bias_reg = 0.f;
-  if (tid < BN && g.bias) bias_reg = g.bias[min(n0 + tid, g.N - 1)];
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias_reg) :: "memory");    // (also retires the bias load before any counted wait)
+  if (g.bias) bias_reg = g.bias[min(n0 + (tid & (BN - 1)), g.N - 1)];   // every wave loads: one more outstanding operation each
+                                                                        // (a plain load: hipcc waits for it at its first use, after the loop)
+  // step 0 needs X(0) and W(0); X(1) (4 copies) and the bias load (the newest 5 operations) may stay in flight -- the bias
+  // is first read after the K loop, behind the vmcnt(0) of the last step
+  if (nk > 1 && g.bias) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   int xs = 0;                                          // X slot of step kt = kt % 3
   for (int kt = 0; kt < nk; ++kt) {
