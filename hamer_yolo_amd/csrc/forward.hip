@@ -197,10 +197,16 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
   const float dscale = 1.0f / sqrtf((float)w->dec_dim_head);
   for (int i = 0; i < w->dec_depth; ++i) {
     const hm_dec_layer& l = w->layers[i];
-    // self-attention over a single token: softmax == 1, so out = to_out(v) (pose_transformer.py:75-86)
+    // self-attention over a single token: softmax == 1, so out = to_out(to_v(LN(x))) (pose_transformer.py:75-86); with the
+    // folded matrix sa_w = to_out . to_v that is one linear.  (Folding the PreNorm LayerNorms into the linears as well was
+    // tried: every workgroup redoing the row statistics costs what the 18 LayerNorm launches cost.)
     HM_TRY(hm_layernorm(xd, l.ln0_g, l.ln0_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));
-    HM_TRY(hm_linear_f32(hd, dim, l.sa_v_w, dim, nullptr, nullptr, 0, t1, inner, B, inner, dim, 0, stream));
-    HM_TRY(hm_linear_f32(t1, inner, l.sa_out_w, inner, l.sa_out_b, xd, dim, xd, dim, B, dim, inner, 0, stream));
+    if (l.sa_w) {
+      HM_TRY(hm_linear_f32(hd, dim, l.sa_w, dim, l.sa_out_b, xd, dim, xd, dim, B, dim, dim, 0, stream));
+    } else {
+      HM_TRY(hm_linear_f32(hd, dim, l.sa_v_w, dim, nullptr, nullptr, 0, t1, inner, B, inner, dim, 0, stream));
+      HM_TRY(hm_linear_f32(t1, inner, l.sa_out_w, inner, l.sa_out_b, xd, dim, xd, dim, B, dim, inner, 0, stream));
+    }
     // cross-attention on the backbone tokens (pose_transformer.py:111-124)
     HM_TRY(hm_layernorm(xd, l.ln1_g, l.ln1_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));
     HM_TRY(hm_linear_f32(hd, dim, l.ca_q_w, dim, nullptr, nullptr, 0, t1, inner, B, inner, dim, 0, stream));

@@ -119,6 +119,9 @@ class HamerEngine:
                 setattr(l, f"ln{j}_b", L.ptr(f32(sd[p + f"{j}.norm.bias"])))
             l.sa_v_w = L.ptr(f32(sd[p + "0.fn.to_qkv.weight"][2 * inner:3 * inner]))
             l.sa_out_w, l.sa_out_b = L.ptr(f32(sd[p + "0.fn.to_out.0.weight"])), L.ptr(f32(sd[p + "0.fn.to_out.0.bias"]))
+            # one token: softmax == 1, so self-attention is to_out(to_v(.)) -- folded into one [dim][dim] matrix in fp64
+            l.sa_w = L.ptr(f32((sd[p + "0.fn.to_out.0.weight"].to(self.device, torch.float64)
+                                @ sd[p + "0.fn.to_qkv.weight"][2 * inner:3 * inner].to(self.device, torch.float64)).float()))
             l.ca_q_w = L.ptr(f32(sd[p + "1.fn.to_q.weight"]))
             l.ca_out_w, l.ca_out_b = L.ptr(f32(sd[p + "1.fn.to_out.0.weight"])), L.ptr(f32(sd[p + "1.fn.to_out.0.bias"]))
             l.ff1_w, l.ff1_b = L.ptr(f32(sd[p + "2.fn.net.0.weight"])), L.ptr(f32(sd[p + "2.fn.net.0.bias"]))

@@ -65,7 +65,7 @@ class VitBlock(C.Structure):
 
 
 class DecLayer(C.Structure):
-    _fields_ = [(n, vp) for n in ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "sa_v_w", "sa_out_w",
+    _fields_ = [(n, vp) for n in ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "sa_v_w", "sa_w", "sa_out_w",
                                   "sa_out_b", "ca_q_w", "ca_out_w", "ca_out_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
 
 

@@ -138,6 +138,7 @@ int hm_patch_im2col(const float* img, void* patches, int B, int img_h, int img_w
 int hm_linear_f32(const float* x, int ldx, const float* W, int ldw, const float* bias, const float* resid, int ldr,
                   float* out, int ldo, int M, int N, int K, int act, void* stream);
 
+
 /* out[b][:] = vec[:] for b < B (the zero-token embedding, pose_transformer.py:350-354). */
 int hm_broadcast_rows(const float* vec, float* out, int B, int D, void* stream);
 
@@ -207,6 +208,8 @@ typedef struct hm_vit_block {
 typedef struct hm_dec_layer {
   const float *ln0_g, *ln0_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   const float* sa_v_w;    /* rows [2*inner, 3*inner) of to_qkv.weight: [inner][dim]  */
+  const float* sa_w;      /* optional: to_out.weight . sa_v_w, [dim][dim] -- self-attention over one token is linear
+                             (softmax == 1), so the two projections fold into one                                    */
   const float *sa_out_w, *sa_out_b;
   const float* ca_q_w;
   const float *ca_out_w, *ca_out_b;
