@@ -292,19 +292,11 @@ __global__ __launch_bounds__(64 * NWAVE, 3) void vit_attention_kernel(const type
 
 template <class TT, bool MX8 = false>
 int launch_att(const void* qkv, void* out, int B, int heads, float scale, hipStream_t s, void* out_scales = nullptr) {
-  static bool attr_set = false;
-  static int n_cu = 0;
+  static HmLdsOnce lds_once;
   auto kern = vit_attention_kernel<TT, MX8>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "hm_vit_attention: cannot raise dynamic LDS limit");
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "hm_vit_attention: cannot query the device");
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  if (const int rc = lds_once.ensure((const void*)kern, ATT_LDS, "hm_vit_attention: cannot raise dynamic LDS limit")) return rc;
+  const int n_cu = hm_device_cu_count();
+  if (n_cu <= 0) return hm_set_error(HM_ERR_HIP, "hm_vit_attention: cannot query the device");
   const int items = B * heads;
   // persistent: one workgroup per CU, every workgroup the same number of items when items % CUs == 0
   const int per = (items + n_cu - 1) / n_cu, grid = (items + per - 1) / per;

@@ -612,12 +612,8 @@ int launch_fp8(const KArgs& g, hipStream_t s) {
   constexpr int LDS = 2 * (2 * 256 * 128 + 4 * 256) + 256 * 8 + 256 * 8;
   static_assert(LDS >= 8 * epi_stage_bytes(4, 8), "epilogue staging fits in the ring");
   auto kern = gemm_fp8_kernel<EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "hm_gemm_fp8: cannot raise the dynamic LDS limit");
-    attr_set = true;
-  }
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_gemm_fp8: cannot raise the dynamic LDS limit")) return rc;
   const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, g);
   return hm_check_launch("hm_gemm_fp8");
@@ -754,12 +750,8 @@ int launch_rs(const KArgs& g, hipStream_t s) {
   constexpr int LDS = 5 * 256 * 128;                                    // 163,840 B: all of it
   static_assert(LDS >= 8 * epi_stage_bytes(4, 8) + 256 * 8 + 2 * 256 * 4, "epilogue staging + vectors fit");
   auto kern = gemm_x3_kernel<T, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "gemm: cannot raise the dynamic LDS limit");
-    attr_set = true;
-  }
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
   const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, g);
   return hm_check_launch("hm_gemm");
@@ -783,12 +775,8 @@ int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
   constexpr int RING = STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI);
   constexpr int LDS = (RING > EPIB ? RING : EPIB) + BM * 8 + BN * 8;     // + row statistics + column vectors
   auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "gemm: cannot raise the dynamic LDS limit");
-    attr_set = true;
-  }
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * ((EPI == HM_EPI_F32 && !CONV) ? g.ksplit : 1);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, s, g);
   return hm_check_launch(what);
@@ -814,13 +802,15 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 9: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 1>(g, s, "hm_gemm");   // + s_setprio around the MFMA cluster
     case 10: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");  // + loads issued between the two sub-steps
     case 11: return launch_cfg<T, EPI, 4, 2, 4, 8, 4, false, 32, 1>(g, s, "hm_gemm");  // 256x256x32, 4 stages, setprio
-    case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // ABLATION: LDS-DMA + waits + barriers only
-    case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ABLATION: ds_read + MFMA + barriers, no loads
-    case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // ABLATION: no epilogue
+#ifdef HM_ABLATIONS   // timing ablations with WRONG results: only in a -DHM_ABLATIONS build (tools/bench_gemm_ab.py), never in the shipped library
+    case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // LDS-DMA + waits + barriers only
+    case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ds_read + MFMA + barriers, no loads
+    case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // no epilogue
+    case 18: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 97>(g, s, "hm_gemm"); // every tile loads operand panel 0 (pure L2 hits)
+#endif
     case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
     case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
-    case 18: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 97>(g, s, "hm_gemm"); // EXPERIMENT (wrong results): every tile loads operand panel 0 (pure L2 hits)
     case 24:                                                                           // X two K-steps ahead in a 3-slot ring (gemm_x3_kernel)
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
         if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_rs<T, EPI>(g, s);   // 32-bit lane offsets
@@ -845,10 +835,19 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 // the LDS-DMA bytes per flop of the 128x128 one (the K loop is bound by the global->LDS fill, not by the MFMA pipe) and
 // wins by 15 % at M = 12288 -- as long as its tiles fill the CUs; small and mid-sized problems keep the 128x128 tile
 // (less padding and round waste, 2 workgroups per CU).
+bool variant_ok(int v) {
+  if (v == -1) return true;
+#ifdef HM_ABLATIONS
+  if (v == 14 || v == 15 || v == 18 || v == 20) return true;
+#endif
+  return (v >= 0 && v <= 11) || (v >= 21 && v <= 24);
+}
+
 int pick_variant(const KArgs& g) {
   if (g_variant == -2) {
-    const char* e = getenv("HM_GEMM_VARIANT");
-    g_variant = e ? atoi(e) : -1;
+    const char* e = getenv("HM_GEMM_VARIANT");     // tuning runs only; an unknown or ablation id is ignored, never obeyed
+    const int v = e ? atoi(e) : -1;
+    g_variant = variant_ok(v) ? v : -1;
   }
   if (g_variant >= 0) return g_variant;
   if (g.M < 1024 || g.N < 512) return 0;
@@ -916,7 +915,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (v < -1 || v > 24) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..24 (14, 15, 18, 20: timing ablations with wrong results)");
+  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..24");
   g_variant = v;
   return HM_OK;
 }

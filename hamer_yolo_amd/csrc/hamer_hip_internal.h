@@ -14,3 +14,21 @@ struct HmProfScope {
   HmProfScope(int kind, int epi, int M, int N, int K, hipStream_t st) : idx(hm_prof_push(kind, epi, M, N, K, st)), s(st) {}
   ~HmProfScope() { hm_prof_pop(idx, s); }
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device), safe under concurrent host
+// threads: one static HmLdsOnce per launch site.  Returns HM_OK or sets the error string.
+#include <mutex>
+struct HmLdsOnce {
+  std::mutex mu;
+  unsigned long long done = 0;      // bit d set: device d has the attribute (devices >= 64: set on every call)
+  int ensure(const void* kernel, int lds_bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hm_set_error(HM_ERR_HIP, what);
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 64 && ((done >> dev) & 1ull)) return HM_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return hm_set_error(HM_ERR_HIP, what);
+    if (dev < 64) done |= 1ull << dev;
+    return HM_OK;
+  }
+};
+int hm_device_cu_count(void);   // multiProcessorCount of the current device (cached per device), <= 0 on error

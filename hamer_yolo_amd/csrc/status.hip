@@ -18,5 +18,18 @@ int hm_check_launch(const char* what) {
   return HM_ERR_HIP;
 }
 
+int hm_device_cu_count(void) {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 64 && cus[dev] > 0) return cus[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  if (dev < 64) cus[dev] = n;
+  return n;
+}
+
 extern "C" int hm_version(void) { return HM_VERSION; }
 extern "C" const char* hm_last_error_string(void) { return g_err; }

@@ -116,13 +116,30 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ r
 }
 
 // ------------------------------------------------------------------------------- NMS
-struct Cand { float x1, y1, x2, y2, conf, cls; int idx, pad; };
-constexpr int NMS_CAP = 16384;       // >= 15120 candidates of a 384x640 input
+// general.py:611-703 takes any (1, n, 5+nc): 15120 rows for a 384x640 letterbox, 18900 for 480x640, 25200 for 640x640.
+// The confidence filter writes the surviving box of row i to cand[i] (no compaction of the boxes) and appends one sort key
+// per survivor -- score in the high word, ~row in the low word -- to a compact key list.  One workgroup then sorts the
+// keys (in LDS when <= 16384 survive, in the workspace otherwise: only a degenerate prediction does that), keeps the best
+// 30000 as the reference does (max_nms), and runs the greedy suppression.  Equal scores: lower row first, as a stable
+// descending argsort gives.
+struct Cand { float x1, y1, x2, y2, conf, cls; int pad0, pad1; };
+constexpr int NMS_LDS_KEYS = 16384;  // survivors sorted in LDS
+constexpr int NMS_MAX_NMS = 30000;   // general.py:625
+constexpr int NMS_MAX_ROWS = 1 << 20;
 constexpr int NMS_BOXCACHE = 1024;
-constexpr int NMS_LDS = NMS_CAP * 8 + NMS_BOXCACHE * 16 + NMS_CAP / 8 + 16 + 4096;
+constexpr int NMS_SUPP_WORDS = 1024; // 32768 bits >= NMS_MAX_NMS
+constexpr int NMS_LDS = NMS_LDS_KEYS * 8 + NMS_BOXCACHE * 16 + NMS_SUPP_WORDS * 4 + 16 + 4096;
+
+__host__ __device__ inline int nms_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+__device__ __forceinline__ unsigned f2sortable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 __global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict__ pred, int n, int nc, float conf_thres,
-                                                         unsigned class_mask, Cand* __restrict__ cand, int* __restrict__ counter) {
+                                                         unsigned class_mask, Cand* __restrict__ cand,
+                                                         unsigned long long* __restrict__ keys, int* __restrict__ counter) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float* p = pred + (size_t)i * (5 + nc);
@@ -136,40 +153,27 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict
   if (!(best > conf_thres)) return;
   if (!((class_mask >> bj) & 1u)) return;
   const float hw = p[2] / 2, hh = p[3] / 2;                          // xywh2xyxy (general.py:268-275)
-  Cand c{p[0] - hw, p[1] - hh, p[0] + hw, p[1] + hh, best, (float)bj, i, 0};
-  const int slot = atomicAdd(counter, 1);
-  cand[slot] = c;
+  cand[i] = Cand{p[0] - hw, p[1] - hh, p[0] + hw, p[1] + hh, best, (float)bj, 0, 0};
+  keys[atomicAdd(counter, 1)] = ((unsigned long long)f2sortable(best) << 32) | (0xFFFFFFFFu - (unsigned)i);
 }
 
-__device__ __forceinline__ unsigned f2sortable(float f) {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__global__ __launch_bounds__(1024) void nms_kernel(const Cand* __restrict__ cand, const int* __restrict__ counter,
+__global__ __launch_bounds__(1024) void nms_kernel(const Cand* __restrict__ cand, unsigned long long* gkeys, const int* __restrict__ counter,
                                                    float iou_thres, int agnostic, int max_det, hm_letterbox_plan pl,
                                                    int do_scale, float* __restrict__ dets, int* __restrict__ count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* keys = (unsigned long long*)smem;                       // NMS_CAP
-  float4* bcache = (float4*)(smem + NMS_CAP * 8);                             // NMS_BOXCACHE
-  unsigned* supp = (unsigned*)(smem + NMS_CAP * 8 + NMS_BOXCACHE * 16);       // NMS_CAP / 32 words
-  int* kept = (int*)(smem + NMS_CAP * 8 + NMS_BOXCACHE * 16 + NMS_CAP / 8 + 16);   // <= 1024 entries
+  float4* bcache = (float4*)(smem + NMS_LDS_KEYS * 8);                              // NMS_BOXCACHE
+  unsigned* supp = (unsigned*)(smem + NMS_LDS_KEYS * 8 + NMS_BOXCACHE * 16);        // NMS_SUPP_WORDS
+  int* kept = (int*)(smem + NMS_LDS_KEYS * 8 + NMS_BOXCACHE * 16 + NMS_SUPP_WORDS * 4 + 16);   // <= 1024 entries
   const int tid = threadIdx.x;
   int n = *counter;
-  n = n < NMS_CAP ? n : NMS_CAP;
-  int P = 1;
-  while (P < n) P <<= 1;
-  for (int j = tid; j < P; j += 1024) {
-    unsigned long long key = 0ull;
-    if (j < n) {
-      const Cand c = cand[j];
-      key = ((unsigned long long)f2sortable(c.conf) << 32) | ((unsigned long long)(0x3FFF - c.idx) << 14) | (unsigned)j;
-    }
-    keys[j] = key;
-  }
-  for (int j = tid; j < NMS_CAP / 32; j += 1024) supp[j] = 0u;
+  const int P = nms_pow2(n);
+  const bool in_lds = n <= NMS_LDS_KEYS;
+  unsigned long long* keys = in_lds ? (unsigned long long*)smem : gkeys;            // the workspace holds nms_pow2(rows) keys
+  if (in_lds) { for (int j = tid; j < P; j += 1024) keys[j] = j < n ? gkeys[j] : 0ull; }
+  else { for (int j = n + tid; j < P; j += 1024) keys[j] = 0ull; }
+  for (int j = tid; j < NMS_SUPP_WORDS; j += 1024) supp[j] = 0u;
   __syncthreads();
-  // bitonic sort, descending
+  // bitonic sort, descending (a real key has its top bit set: scores are > conf_thres >= 0, so the zero padding sorts last)
   for (int k = 2; k <= P; k <<= 1)
     for (int s = k >> 1; s > 0; s >>= 1) {
       for (int j = tid; j < P; j += 1024) {
@@ -182,9 +186,11 @@ __global__ __launch_bounds__(1024) void nms_kernel(const Cand* __restrict__ cand
       }
       __syncthreads();
     }
+  n = n < NMS_MAX_NMS ? n : NMS_MAX_NMS;                                        // x[x[:, 4].argsort(descending=True)[:max_nms]]
   const float off = agnostic ? 0.0f : 4096.0f;                                 // c = cls * max_wh (general.py:684)
+  auto row_of = [&](int j) { return (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull)); };
   auto load_box = [&](int j) {
-    const Cand c = cand[(int)(keys[j] & 0x3FFFu)];
+    const Cand c = cand[row_of(j)];
     const float o = c.cls * off;
     return make_float4(c.x1 + o, c.y1 + o, c.x2 + o, c.y2 + o);
   };
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const Cand* __restrict__ cand
   __syncthreads();
   if (tid == 0) *count = nk;
   for (int r = tid; r < nk; r += 1024) {
-    const Cand c = cand[(int)(keys[kept[r]] & 0x3FFFu)];
+    const Cand c = cand[row_of(kept[r])];
     float b[4] = {c.x1, c.y1, c.x2, c.y2};
     if (do_scale) {                                                            // scale_coords + clip + round
       const float lim[4] = {(float)pl.src_w, (float)pl.src_h, (float)pl.src_w, (float)pl.src_h};
@@ -388,34 +394,32 @@ extern "C" int hm_yolo_decode(const float* raw, int ldraw, float* pred, int row0
 }
 
 extern "C" size_t hm_nms_workspace_bytes(int n) {
-  if (n <= 0) return 0;
-  return 256 + (size_t)(n < NMS_CAP ? n : NMS_CAP) * sizeof(Cand);
+  if (n <= 0 || n > NMS_MAX_ROWS) return 0;
+  return 256 + (size_t)nms_pow2(n) * 8 + (size_t)n * sizeof(Cand);      // counter | sort keys | one box per prediction row
 }
 
 extern "C" int hm_yolo_nms(const float* pred, int n, int nc, float conf_thres, float iou_thres, unsigned class_mask,
                            int agnostic, int max_det, const hm_letterbox_plan* plan, float* dets, int* count, void* workspace,
                            size_t workspace_bytes, void* stream_) {
   if (!pred || !dets || !count || !workspace) return hm_set_error(HM_ERR_ARG, "hm_yolo_nms: null pointer");
-  if (n <= 0 || n > NMS_CAP || nc <= 0 || nc > 32 || max_det <= 0 || max_det > 1024)
-    return hm_set_error(HM_ERR_ARG, "hm_yolo_nms: need 0 < n <= 16384, 0 < nc <= 32, 0 < max_det <= 1024");
+  if (n <= 0 || n > NMS_MAX_ROWS || nc <= 0 || nc > 32 || max_det <= 0 || max_det > 1024)
+    return hm_set_error(HM_ERR_ARG, "hm_yolo_nms: need 0 < n <= 1048576, 0 < nc <= 32, 0 < max_det <= 1024");
+  if (!(conf_thres >= 0.0f)) return hm_set_error(HM_ERR_ARG, "hm_yolo_nms: conf_thres must be >= 0");
   if (workspace_bytes < hm_nms_workspace_bytes(n) || ((uintptr_t)workspace & 15))
     return hm_set_error(HM_ERR_ARG, "hm_yolo_nms: workspace too small or misaligned");
   hipStream_t s = (hipStream_t)stream_;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_LDS) != hipSuccess)
-      return hm_set_error(HM_ERR_HIP, "hm_yolo_nms: cannot raise dynamic LDS limit");
-    attr_set = true;
-  }
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)nms_kernel, NMS_LDS, "hm_yolo_nms: cannot raise dynamic LDS limit")) return rc;
   int* counter = (int*)workspace;
-  Cand* cand = (Cand*)((char*)workspace + 256);
+  unsigned long long* keys = (unsigned long long*)((char*)workspace + 256);
+  Cand* cand = (Cand*)((char*)workspace + 256 + (size_t)nms_pow2(n) * 8);
   if (hipMemsetAsync(counter, 0, 256, s) != hipSuccess) return hm_set_error(HM_ERR_HIP, "hm_yolo_nms: memset failed");
   HmProfScope prof(HM_K_OTHER, 5, n, nc, max_det, s);
-  hipLaunchKernelGGL(nms_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pred, n, nc, conf_thres, class_mask, cand, counter);
+  hipLaunchKernelGGL(nms_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pred, n, nc, conf_thres, class_mask, cand, keys, counter);
   hm_letterbox_plan pl;
   memset(&pl, 0, sizeof(pl));
   if (plan) pl = *plan;
-  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), NMS_LDS, s, cand, counter, iou_thres, agnostic, max_det, pl, plan ? 1 : 0, dets, count);
+  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), NMS_LDS, s, cand, keys, counter, iou_thres, agnostic, max_det, pl, plan ? 1 : 0, dets, count);
   return hm_check_launch("hm_yolo_nms");
 }
 

@@ -1,5 +1,11 @@
 """HamerEngine: device-resident HaMeR weights + one-call forward through libhamer_hip.
 
+Operand type.  The checkpoint holds fp32 weights (models/__init__.py:46) and the reference computes in fp32; the 1e-3
+parity bar is against that.  Rounding the weights to bf16 (8 significant bits) alone moves pose / shape by 1.3-1.9e-3
+on the ViT-H geometry, rounding to fp16 (11 bits) by 1.7e-4 (tools/precision_study.py), at the same
+MFMA rate -- so the default operand type is fp16; ``dtype=torch.bfloat16`` stays selectable for checkpoints whose
+activations need the wider exponent.
+
 Load time (host, once): GEMM matrices are converted to the 16-bit operand type and laid out
 [N][K] as nn.Linear stores them; the positional embedding is folded to ``pos[1:] + pos[0]``
 (vit.py:327); the six decoder ``to_kv`` matrices are stacked into one [6*1024][1280] GEMM
@@ -29,7 +35,7 @@ class ForwardContext:
 
 class HamerEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], mano: Dict[str, torch.Tensor],
-                 cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.bfloat16, fold_ln: Optional[bool] = None,
+                 cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.float16, fold_ln: Optional[bool] = None,
                  fp8: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise L.HipLibraryError("HamerEngine needs an MI355X (HIP device); there is no CPU fallback")
@@ -69,8 +75,9 @@ class HamerEngine:
             fp8 = os.environ.get("HAMER_FP8", "0") == "1"
         self.fp8 = bool(fp8)
         if self.fp8:
-            if dtype != torch.bfloat16 or v.embed_dim % 128 != 0:
-                raise L.HipLibraryError("the fp8 path needs dtype=bfloat16 and embed_dim % 128 == 0")
+            if v.embed_dim % 128 != 0:
+                raise L.HipLibraryError("the fp8 path needs embed_dim % 128 == 0")
+            dtype = self.dtype = torch.bfloat16       # the 16-bit side of the fp8 configuration (proj operand, kv) is bf16
             self.fold_ln = False
             from .quant import quantize_weight_e4m3
 

@@ -33,14 +33,14 @@ def _read_state_dict(path: str):
     return {k: v for k, v in sd.items() if isinstance(v, torch.Tensor)}
 
 
-def load_hamer(checkpoint_path=DEFAULT_CHECKPOINT, dtype=torch.bfloat16):
+def load_hamer(checkpoint_path=DEFAULT_CHECKPOINT, dtype=torch.float16):
     checkpoint_path = str(checkpoint_path)
     if checkpoint_path.startswith("synthetic"):
         seed = int(checkpoint_path.split(":")[1]) if ":" in checkpoint_path else 0
         model_cfg = get_config(None)
         model_cfg.MODEL.BBOX_SHAPE = [192, 256]
         dev = "cuda" if torch.cuda.is_available() else "cpu"
-        sd = synth.hamer_state_dict(synth.HamerConfig(), seed=seed, device=dev, bf16_representable=True)
+        sd = synth.hamer_state_dict(synth.HamerConfig(), seed=seed, device=dev)
         return HAMER(model_cfg, sd, MANO.synthetic(seed), dtype=dtype), model_cfg
 
     model_cfg = str(Path(checkpoint_path).parent.parent / "model_config.yaml")

@@ -14,7 +14,7 @@ from .mano_wrapper import MANO
 
 
 class HAMER:
-    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], mano: MANO, dtype=torch.bfloat16,
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], mano: MANO, dtype=torch.float16,
                  hamer_cfg: Optional[synth.HamerConfig] = None):
         self.cfg = cfg
         self.mano = mano

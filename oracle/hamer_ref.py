@@ -15,8 +15,9 @@ reference's own modules loaded by file path on seeded weights --
 the outputs of those runs are committed under tests/golden/.
 
 Every function takes a flat ``state_dict`` keyed like the reference checkpoint.
-``emu`` selects the bf16 emulation used for tight kernel-level checks: activations and
-weights are rounded to bf16 exactly where the HIP path rounds them, arithmetic stays fp32.
+``emu`` selects the 16-bit emulation used for tight kernel-level checks (True / "bf16": bfloat16,
+"fp16": half, "fp8": the MXFP8 configuration): activations and weights are rounded exactly where
+the HIP path rounds them, arithmetic stays fp32.
 """
 from __future__ import annotations
 
@@ -30,7 +31,10 @@ Tensor = torch.Tensor
 
 
 def _q(x: Tensor, emu) -> Tensor:
-    return x.to(torch.bfloat16).to(torch.float32) if emu else x
+    """Round to the 16-bit operand type the HIP path uses: emu == "fp16" -> half, any other true value -> bfloat16."""
+    if not emu:
+        return x
+    return x.to(torch.float16 if emu == "fp16" else torch.bfloat16).to(torch.float32)
 
 
 def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], emu) -> Tensor:
@@ -58,7 +62,7 @@ def vit_attention(sd, h: Tensor, p: str, vit, emu=False) -> Tensor:
     """Attention.forward, vit.py:110-126."""
     B, N, C = h.shape
     if emu == "fp8":
-        qkv = _q(_linear_fp8(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]), True)
+        qkv = _q(_linear_fp8(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]), True)   # fp8 path: bf16 outputs
     else:
         qkv = _q(_linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], emu), emu)
     qkv = qkv.reshape(B, N, 3, vit.heads, -1).permute(2, 0, 3, 1, 4)
@@ -69,7 +73,7 @@ def vit_attention(sd, h: Tensor, p: str, vit, emu=False) -> Tensor:
         # the PV MFMA and keeps the row sum in fp32
         s = (q @ k.transpose(-2, -1)) * scale
         pun = torch.exp(s - s.amax(dim=-1, keepdim=True))
-        o = _q((_q(pun, True) @ v) / pun.sum(dim=-1, keepdim=True), True)
+        o = _q((_q(pun, emu) @ v) / pun.sum(dim=-1, keepdim=True), emu)
     else:
         q = q * scale
         attn = (q @ k.transpose(-2, -1)).softmax(dim=-1)

@@ -77,23 +77,32 @@ def letterbox(img_bgr: np.ndarray, new_shape: int = 640, stride: int = 32, color
 
 
 # ----------------------------------------------------------------------------- fused forward (A3, A4)
-def _conv(x: Tensor, wb: Tuple[Tensor, Tensor], k: int, s: int, act: bool = True) -> Tensor:
-    y = F.conv2d(x, wb[0], wb[1], stride=s, padding=k // 2)
-    return F.silu(y) if act else y
+def _h(t: Tensor, emu) -> Tensor:
+    """emu == "fp16": round to half where hm_conv2d_nhwc stores half (weights at load time, every activation tensor)."""
+    return t.half().float() if emu else t
+
+
+def _conv(x: Tensor, wb: Tuple[Tensor, Tensor], k: int, s: int, act: bool = True, emu=False, out_f32: bool = False) -> Tensor:
+    y = F.conv2d(x, _h(wb[0], emu), wb[1], stride=s, padding=k // 2)      # fp32 accumulation, fp32 bias
+    y = F.silu(y) if act else y
+    return y if out_f32 else _h(y, emu)
 
 
 def yolo_forward(layers, fused: Dict[str, Tuple[Tensor, Tensor]], x: Tensor, nc: int = 3,
-                 anchors: Sequence[Sequence[int]] = (), strides: Sequence[int] = (8, 16, 32)) -> Tuple[Tensor, List[Tensor]]:
+                 anchors: Sequence[Sequence[int]] = (), strides: Sequence[int] = (8, 16, 32), emu=False) -> Tuple[Tensor, List[Tensor]]:
     """Model.forward_once over the fused graph (yolo.py:609-639) + IDetect.fuseforward (yolo.py:148-184).
-    x: (B,3,H,W) in [0,1].  Returns (pred (B, sum(3*ny*nx), 5+nc), the three raw head maps)."""
+    x: (B,3,H,W) in [0,1].  Returns (pred (B, sum(3*ny*nx), 5+nc), the three raw head maps).
+    ``emu="fp16"``: the arithmetic of the HIP path (reference GPU branch, detector.py:110-112 ``half()``): half weights and
+    activations, fp32 accumulation and bias, the three head maps and the decode in fp32."""
     ys: List[Optional[Tensor]] = []
+    x = _h(x, emu)
     for i, (frm, kind, args) in enumerate(layers):
         srcs = frm if isinstance(frm, list) else [frm]
         inp = [x if (s == -1 and i == 0) else ys[s if s >= 0 else i + s] for s in srcs]
         if kind == "conv":
-            y = _conv(inp[0], fused[f"model.{i}.conv"], args[1], args[2])
+            y = _conv(inp[0], fused[f"model.{i}.conv"], args[1], args[2], emu=emu)
         elif kind == "repconv":
-            y = _conv(inp[0], fused[f"model.{i}.rbr_reparam"], 3, 1)
+            y = _conv(inp[0], fused[f"model.{i}.rbr_reparam"], 3, 1, emu=emu)
         elif kind == "mp":
             y = F.max_pool2d(inp[0], 2, 2)
         elif kind == "up":
@@ -101,7 +110,7 @@ def yolo_forward(layers, fused: Dict[str, Tuple[Tensor, Tensor]], x: Tensor, nc:
         elif kind == "concat":
             y = torch.cat(inp, 1)
         elif kind == "sppcspc":                                  # common.py:279-284
-            cv = lambda j, t, k: _conv(t, fused[f"model.{i}.cv{j}.conv"], k, 1)
+            cv = lambda j, t, k: _conv(t, fused[f"model.{i}.cv{j}.conv"], k, 1, emu=emu)
             x1 = cv(4, cv(3, cv(1, inp[0], 1), 3), 1)
             y1 = cv(6, cv(5, torch.cat([x1] + [F.max_pool2d(x1, k, 1, k // 2) for k in (5, 9, 13)], 1), 1), 3)
             y = cv(7, torch.cat((y1, cv(2, inp[0], 1)), dim=1), 1)
@@ -109,7 +118,7 @@ def yolo_forward(layers, fused: Dict[str, Tuple[Tensor, Tensor]], x: Tensor, nc:
             z, raws = [], []
             no = nc + 5
             for l, t in enumerate(inp):
-                r = _conv(t, fused[f"model.{i}.m.{l}"], 1, 1, act=False)
+                r = _conv(t, fused[f"model.{i}.m.{l}"], 1, 1, act=False, emu=emu, out_f32=True)
                 bs, _, ny, nx = r.shape
                 r = r.view(bs, 3, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
                 raws.append(r)
@@ -161,7 +170,7 @@ def xywh2xyxy(x: Tensor) -> Tensor:
 def non_max_suppression(prediction: Tensor, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
                         max_det: int = 300) -> List[Tensor]:
     """utils/general.py:611-703 (best-class branch, no labels, no merge)."""
-    max_wh = 4096
+    max_wh, max_nms = 4096, 30000
     xc = prediction[..., 4] > conf_thres
     output = [torch.zeros((0, 6))] * prediction.shape[0]
     for xi, x in enumerate(prediction):
@@ -176,6 +185,8 @@ def non_max_suppression(prediction: Tensor, conf_thres=0.25, iou_thres=0.45, cla
             x = x[(x[:, 5:6] == torch.tensor(classes)).any(1)]
         if not x.shape[0]:
             continue
+        if x.shape[0] > max_nms:                                   # general.py:679-680 (stable: equal scores keep row order)
+            x = x[torch.argsort(x[:, 4], descending=True, stable=True)[:max_nms]]
         c = x[:, 5:6] * (0 if agnostic else max_wh)
         i = nms_greedy(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
         output[xi] = x[i]
@@ -195,11 +206,11 @@ def scale_coords(img1_shape, coords: Tensor, img0_shape) -> Tensor:
 
 
 def detect(layers, fused, img_bgr: np.ndarray, nc=3, anchors=(), conf_thres=0.25, iou_thres=0.35,
-           classes=(0, 1, 2), agnostic=True):
-    """Detector.detect, yolo/detector.py:106-153 (CPU branch: fp32)."""
+           classes=(0, 1, 2), agnostic=True, emu=False):
+    """Detector.detect, yolo/detector.py:106-153 (CPU branch: fp32; ``emu="fp16"``: the GPU branch's half arithmetic)."""
     chw, g = letterbox(img_bgr)
     x = torch.from_numpy(chw).float() / 255.0
-    pred, _ = yolo_forward(layers, fused, x[None], nc, anchors)
+    pred, _ = yolo_forward(layers, fused, x[None], nc, anchors, emu=emu)
     dets = non_max_suppression(pred, conf_thres, iou_thres, list(classes), agnostic)
     out_list = []
     for det in dets:

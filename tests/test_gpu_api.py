@@ -29,7 +29,7 @@ def hi():
 
 def _oracle_pipeline(frame, dets, k_real):
     cfg = synth.HamerConfig()
-    sd = synth.hamer_state_dict(cfg, seed=0, bf16_representable=True)
+    sd = synth.hamer_state_dict(cfg, seed=0)
     mp = synth.mano_params(seed=0)
     mean = 255.0 * np.array([0.485, 0.456, 0.406]); std = 255.0 * np.array([0.229, 0.224, 0.225])
     batch = crop_ref.prepare_batch_bbox(frame, dets, mean, std)

@@ -111,7 +111,7 @@ def test_vith_forward_fp8_vs_fp8_oracle(golden_dir):
     from oracle import hamer_ref as R
     g = np.load(os.path.join(golden_dir, "hamer_vith.npz"))
     cfg = synth.HamerConfig()
-    sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]), device="cuda", bf16_representable=True)
+    sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]), device="cuda")
     mp = synth.mano_params(seed=0)
     eng = HamerEngine(sd, mp, cfg, fp8=True)
     assert eng.fp8
@@ -124,7 +124,7 @@ def test_vith_forward_fp8_vs_fp8_oracle(golden_dir):
         assert torch.isfinite(out[k]).all()
     d_pose = (out["pose6d"].cpu() - ref["pose6d"]).abs().max().item()
     d_vert = (out["pred_vertices"].cpu() - ref["pred_vertices"]).abs().max().item()
-    g_pose = np.abs(out["pose6d"].cpu().numpy() - g["pose6d"]).max()
+    g_pose = np.abs(out["pose6d"].cpu().numpy() - g["pose6d"][:2]).max()
     print(f"fp8: |pose6d - fp8 oracle| {d_pose:.2e}  |verts - fp8 oracle| {d_vert:.2e}  |pose6d - fp32 reference| {g_pose:.2e}")
     # same quantisation on both sides: what is left are e4m3 rounding flips triggered by fp32 summation order
     assert d_pose < 1e-2 and d_vert < 2e-3

@@ -1,10 +1,13 @@
 """GPU parity of the whole HaMeR forward (hm_hamer_forward through the C ABI).
 
-Fixtures in tests/golden/ were produced by the reference's own modules (tools/gen_golden.py);
-the tolerance of the headline check is north_star's 1e-3 abs on MANO theta (rotation
-matrices) / beta and on the 778 vertices, against the fp32 CPU path on the same inputs and
-the same (bf16-representable) weights.
+Fixtures in tests/golden/ were produced by the reference's own modules (tools/gen_golden.py) on fp32 master
+weights, as a real checkpoint holds them (hamer/hamer/models/__init__.py:46); the engine rounds them to its 16-bit
+operand type itself.  The tolerance of the headline checks is north_star's 1e-3 abs on MANO theta (rotation
+matrices) / beta and on the 778 vertices, against the fp32 CPU path on the same inputs -- met by the default operand
+type fp16; bf16 (8 significant bits) stays selectable and its distance is asserted against the looser, documented
+bound BF16_TOL.
 """
+import json
 import os
 
 import numpy as np
@@ -17,13 +20,30 @@ from hamer_yolo_amd import synth
 from hamer_yolo_amd.engine import HamerEngine
 from oracle import hamer_ref as R
 
-TOL = 1e-3   # BASELINE.json north_star: "within 1e-3 abs"
+TOL = 1e-3        # BASELINE.json north_star: "within 1e-3 abs" (fp16 operands, the default)
+BF16_TOL = 4e-3   # bf16 operands vs the fp32 path on fp32 master weights: weight rounding alone is ~1.5e-3
 
 
-def _engine(cfg, seed, dtype=torch.bfloat16, mano_seed=0, fold_ln=None):
-    sd = synth.hamer_state_dict(cfg, seed=seed, bf16_representable=True)
+def _tol(dtype):
+    return TOL if dtype == torch.float16 else BF16_TOL
+
+
+def _engine(cfg, seed, dtype=torch.float16, mano_seed=0, fold_ln=None):
+    sd = synth.hamer_state_dict(cfg, seed=seed)
     mp = synth.mano_params(seed=mano_seed)
     return HamerEngine(sd, mp, cfg, dtype=dtype, fold_ln=fold_ln), sd, mp
+
+
+def _report(name, **vals):
+    """Achieved distances, kept next to the test log (gpurun_out/ travels back from the GPU box)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **{k: float(v) for k, v in vals.items()}}) + "\n")
+    except OSError:
+        pass
+    print(name, {k: f"{float(v):.2e}" for k, v in vals.items()})
 
 
 # fold_ln: LayerNorm deferred into the neighbouring GEMMs, or run as its own kernel (the default)
@@ -39,18 +59,19 @@ def test_tiny_forward_vs_reference_golden(golden_dir, dtype, fold_ln):
     torch.cuda.synchronize()
     tok = out["tokens"].float().cpu().reshape(3, 192, -1).numpy()
     assert np.abs(tok - g["tokens"]).max() < (6e-2 if dtype == torch.bfloat16 else 8e-3)
-    np.testing.assert_allclose(out["pose6d"].cpu().numpy(), g["pose6d"], atol=TOL, rtol=0)
-    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["betas"], atol=TOL, rtol=0)
-    np.testing.assert_allclose(out["pred_cam"].cpu().numpy(), g["cam"], atol=TOL, rtol=0)
-    np.testing.assert_allclose(out["rotmats"].cpu().numpy(), g["rotmats"], atol=TOL, rtol=0)
-    # bf16-emulating oracle: same rounding points, so the gap is accumulation order only
+    tol = _tol(dtype)
+    np.testing.assert_allclose(out["pose6d"].cpu().numpy(), g["pose6d"], atol=tol, rtol=0)
+    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["betas"], atol=tol, rtol=0)
+    np.testing.assert_allclose(out["pred_cam"].cpu().numpy(), g["cam"], atol=tol, rtol=0)
+    np.testing.assert_allclose(out["rotmats"].cpu().numpy(), g["rotmats"], atol=tol, rtol=0)
+    # 16-bit-emulating oracle: same rounding points, so the gap is accumulation order only
     with torch.no_grad():
         # (the explicit-LN path only: deferred LN rounds x*gamma instead of LN(x))
-        emu = R.hamer_forward(sd, mp, img, cfg, emu=True) if dtype == torch.bfloat16 and not fold_ln else None
+        emu = R.hamer_forward(sd, mp, img, cfg, emu="bf16" if dtype == torch.bfloat16 else "fp16") if not fold_ln else None
         ref = R.hamer_forward(sd, mp, img, cfg, emu=False)
     for k_out, k_ref in (("pred_vertices", "pred_vertices"), ("pred_keypoints_3d", "pred_keypoints_3d"),
                          ("pred_keypoints_2d", "pred_keypoints_2d")):
-        np.testing.assert_allclose(out[k_out].cpu().numpy(), ref[k_ref].numpy(), atol=TOL, rtol=1e-3)
+        np.testing.assert_allclose(out[k_out].cpu().numpy(), ref[k_ref].numpy(), atol=tol, rtol=1e-3)
     np.testing.assert_allclose(out["pred_cam_t"].cpu().numpy(), ref["pred_cam_t"].numpy(), rtol=2e-3)
     if emu is not None:
         np.testing.assert_allclose(out["pose6d"].cpu().numpy(), emu["pose6d"].numpy(), atol=3e-4, rtol=0)
@@ -58,36 +79,64 @@ def test_tiny_forward_vs_reference_golden(golden_dir, dtype, fold_ln):
 
 
 @pytest.mark.parametrize("fold_ln", [True, False])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_vith_forward_vs_reference_golden(golden_dir, dtype, fold_ln):
-    """Full ViT-H/16 + 6-layer decoder; expected values from the reference vit.py / pose_transformer.py."""
+    """Full ViT-H/16 + 6-layer decoder on fp32 master weights; expected values from the reference vit.py / pose_transformer.py."""
     g = np.load(os.path.join(golden_dir, "hamer_vith.npz"))
+    assert int(g["bf16_representable"]) == 0
     cfg = synth.HamerConfig()
-    sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]), device="cuda", bf16_representable=True)
+    sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]), device="cuda")
     mp = synth.mano_params(seed=0)
     eng = HamerEngine(sd, mp, cfg, dtype=dtype, fold_ln=fold_ln)
-    img = synth.normalize_crops(synth.crops_u8(2, seed0=int(g["crop_seed0"])))
+    nb = g["pose6d"].shape[0]
+    img = synth.normalize_crops(synth.crops_u8(nb, seed0=int(g["crop_seed0"])))
     out = eng.forward(img.cuda(), want_tokens=True)
     torch.cuda.synchronize()
-    tok = out["tokens"].float().cpu().reshape(2, 192, 1280)
-    assert np.abs(tok[:, ::16, ::40].numpy() - g["tokens_sub"]).max() < (8e-2 if dtype == torch.bfloat16 else 1e-2)
+    tol = _tol(dtype)
+    tok = out["tokens"].float().cpu().reshape(nb, 192, 1280)
+    assert np.abs(tok[:, ::16, ::40].numpy() - g["tokens_sub"]).max() < (1e-1 if dtype == torch.bfloat16 else 1.5e-2)
     np.testing.assert_allclose(tok.mean((1, 2)).numpy(), g["tokens_mean"], atol=2e-3)
-    np.testing.assert_allclose(out["pose6d"].cpu().numpy(), g["pose6d"], atol=TOL, rtol=0)
-    np.testing.assert_allclose(out["betas"].cpu().numpy(), g["betas"], atol=TOL, rtol=0)
-    np.testing.assert_allclose(out["pred_cam"].cpu().numpy(), g["cam"], atol=TOL, rtol=0)
-    np.testing.assert_allclose(out["rotmats"].cpu().numpy(), g["rotmats"], atol=TOL, rtol=0)
-    # vertices: oracle MANO on the golden pose/shape (MANO itself is pinned against manopth)
-    verts, joints = R.mano_forward(mp, torch.from_numpy(g["betas"]), torch.from_numpy(g["rotmats"]))
-    np.testing.assert_allclose(out["pred_vertices"].cpu().numpy(), verts.numpy(), atol=TOL, rtol=0)
-    np.testing.assert_allclose(out["pred_keypoints_3d"].cpu().numpy(), joints.numpy(), atol=TOL, rtol=0)
+    verts, joints = R.mano_forward(mp, torch.from_numpy(g["betas"]), torch.from_numpy(g["rotmats"]))   # MANO itself is pinned against manopth
+    d = {k: np.abs(out[k].cpu().numpy() - e).max() for k, e in (("pose6d", g["pose6d"]), ("betas", g["betas"]), ("pred_cam", g["cam"]),
+                                                               ("rotmats", g["rotmats"]), ("pred_vertices", verts.numpy()),
+                                                               ("pred_keypoints_3d", joints.numpy()))}
+    _report(f"vith_golden[{str(dtype).split('.')[-1]},fold_ln={fold_ln}]", **d)
+    for k, v in d.items():
+        assert v < (TOL if k in ("pred_vertices", "pred_keypoints_3d") else tol), (k, v)      # the mesh is within 1e-3 for either type
+
+
+def test_batch64_vs_fp32_oracle_at_production_tile():
+    """BASELINE configs[1] as benchmarked: 64 different crops, fp32 master weights, the default operand type (fp16) and
+    the production GEMM tile (M = 12288 -> gemm_x3_kernel), against the fp32 CPU oracle on the same 64 crops:
+    theta (rotation matrices), beta and the 778 vertices within north_star's 1e-3."""
+    cfg = synth.HamerConfig()
+    sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
+    mp = synth.mano_params(seed=0)
+    eng = HamerEngine(sd, mp, cfg)
+    assert eng.dtype == torch.float16
+    img = synth.normalize_crops(synth.crops_u8(64, seed0=1000))
+    out = {k: v.cpu() for k, v in eng.forward(img.cuda()).items()}
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = R.hamer_forward(sd_cpu, mp, img, cfg)
+    rot = torch.cat([ref["global_orient"], ref["hand_pose"]], 1)
+    d = {"rotmats": (out["rotmats"] - rot).abs().max(), "betas": (out["betas"] - ref["betas"]).abs().max(),
+         "pose6d": (out["pose6d"] - ref["pose6d"]).abs().max(), "pred_cam": (out["pred_cam"] - ref["pred_cam"]).abs().max(),
+         "pred_vertices": (out["pred_vertices"] - ref["pred_vertices"]).abs().max(),
+         "pred_keypoints_3d": (out["pred_keypoints_3d"] - ref["pred_keypoints_3d"]).abs().max()}
+    _report("batch64_fp16_vs_fp32_oracle", **d)
+    for k, v in d.items():
+        assert float(v) < TOL, (k, float(v))
 
 
 def test_batch64_is_batch_invariant():
     """BASELINE config 2 size (B=64): per-crop results do not depend on the batch they ride in -- repeated crops give
     identical rows, a batch of 16 (other GEMM tile shapes, same summation order) gives the same numbers, a batch of 8 (split-K
-    path: other summation order, other bf16 rounding flips) stays far inside the 1e-3 parity bar -- and the output is finite."""
+    path: other summation order, other rounding flips) stays far inside the 1e-3 parity bar -- and the output is finite."""
     cfg = synth.HamerConfig()
-    sd = synth.hamer_state_dict(cfg, seed=0, device="cuda", bf16_representable=True)
+    sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
     eng = HamerEngine(sd, synth.mano_params(seed=0), cfg)
     u8 = synth.crops_u8(16, seed0=0)
     img16 = synth.normalize_crops(u8).cuda()
@@ -111,7 +160,7 @@ def test_batches_in_flight_do_not_interfere():
     """HamerEngine.contexts: four different batches issued back to back on two contexts (own stream, workspace, outputs)
     give, each, bit for bit what a lone forward gives."""
     cfg = synth.tiny_config()
-    sd = synth.hamer_state_dict(cfg, seed=5, device="cuda", bf16_representable=True)
+    sd = synth.hamer_state_dict(cfg, seed=5, device="cuda")
     eng = HamerEngine(sd, synth.mano_params(seed=5), cfg)
     B = 6
     imgs = [synth.normalize_crops(synth.crops_u8(B, seed0=100 + 10 * i)).cuda() for i in range(4)]

@@ -115,7 +115,16 @@ def test_letterbox_bit_exact(engine, hw):
     assert (x8[..., 3:] == 0).all()
 
 
+def _fused():
+    layers = arch.yolov7_layers()
+    return layers, fuse.fuse_state_dict(synth.yolo_state_dict(seed=0, nc=3), arch.conv_specs(layers, 3, 3))
+
+
 def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
+    """Whole network, two bounds.  TIGHT: against the oracle in the kernel's own arithmetic (``emu="fp16"``: half weights
+    and activations, fp32 accumulate -- what the reference's GPU branch computes, detector.py:110-112): raw head logits within
+    1e-2, scores within 2e-3 -- an indexing slip in any of the 92 convolutions cannot pass that.  LOOSE: against the fp32
+    reference golden (fp16 rounding noise through 105 layers of |x| <= 15 activations)."""
     g = np.load(os.path.join(golden_dir, "yolo_forward.npz"))
     # the golden input is this image taken as RGB; the detector takes BGR frames (cv2.imread order) and the
     # letterbox kernel swaps to RGB, so hand it the channel-reversed frame.  384x640: the resize is the identity.
@@ -124,23 +133,24 @@ def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
     torch.cuda.synchronize()
     pred = p["pred"].cpu()
     assert pred.shape == (15120, 8) and torch.isfinite(pred).all()
-    ref_rows = torch.from_numpy(g["pred_rows"])
-    got = pred[::9]
-    # fp16 activations through 105 layers vs the fp32 CPU reference (activations reach |15|, so the head logits
-    # carry ~0.03 of fp16 noise): scores within 0.02, boxes within 10 % of their size scale ((2 sigma)^2 doubles
-    # the relative logit error), and the raw head logits within 0.2 (mean 0.01) of the oracle's
-    assert float((got[:, 4:] - ref_rows[:, 4:]).abs().max()) < 2e-2
-    size = ref_rows[:, 2:4].abs().mean(1, keepdim=True).clamp_min(8.0)
-    assert float(((got[:, :4] - ref_rows[:, :4]).abs() / size).max()) < 1e-1
-    layers = arch.yolov7_layers()
-    fused = fuse.fuse_state_dict(synth.yolo_state_dict(seed=0, nc=3), arch.conv_specs(layers, 3, 3))
+    layers, fused = _fused()
     x = synth.frame_u8(384, 640, seed=int(g["frame_seed"])).permute(2, 0, 1).float()[None] / 255.0
     with torch.no_grad():
+        epred, eraws = yolo_ref.yolo_forward(layers, fused, x, 3, arch.ANCHORS, arch.STRIDES, emu="fp16")
         _, raws = yolo_ref.yolo_forward(layers, fused, x, 3, arch.ANCHORS, arch.STRIDES)
-    for (raw, hh, ww), r in zip(p["raws"], raws):                           # r: (1, 3, ny, nx, 8)
+    for (raw, hh, ww), r, r32 in zip(p["raws"], eraws, raws):                # r: (1, 3, ny, nx, 8)
         mine = raw.cpu().reshape(hh, ww, 3, 8).permute(2, 0, 1, 3)
-        d = (mine - r[0]).abs()                               # fp16 rounding noise through 105 layers of |x| <= 15 activations
-        assert float(d.max()) < 0.2 and float(d.mean()) < 0.01
+        d = (mine - r[0]).abs()
+        assert float(d.max()) < 1e-2 and float(d.mean()) < 5e-4, (float(d.max()), float(d.mean()))
+        d32 = (mine - r32[0]).abs()
+        assert float(d32.max()) < 0.3 and float(d32.mean()) < 0.02
+    assert float((pred[:, 4:] - epred[0, :, 4:]).abs().max()) < 2e-3
+    size = epred[0, :, 2:4].abs().mean(1, keepdim=True).clamp_min(8.0)
+    assert float(((pred[:, :4] - epred[0, :, :4]).abs() / size).max()) < 1e-2
+    # loose: the reference's own fp32 output rows
+    ref_rows = torch.from_numpy(g["pred_rows"])
+    got = pred[::9]
+    assert float((got[:, 4:] - ref_rows[:, 4:]).abs().max()) < 3e-2
     np.testing.assert_allclose(pred.double().sum(0).numpy(), g["pred_sum"], rtol=5e-3)
 
 
@@ -169,32 +179,74 @@ def test_nms_exact_on_reference_prediction(engine, golden_dir):
     assert engine.nms(p, 0.25, 0.35, None, True).shape == (0, 6)
 
 
-def test_detector_detect_end_to_end():
-    """Detector.detect on a 540x960 frame.  With random weights the kept set of a greedy NMS is chaotic under
-    fp16-sized score perturbations, so the end-to-end check is (a) the network output against the fp32 oracle
-    on the SAME letterboxed input and (b) the box list against the oracle's non_max_suppression + scale_coords
-    applied to the GPU's own prediction, which must agree exactly."""
-    class Opt:
-        weights = "synthetic:0"; imgsz = 640; augment = True; conf_thres = 0.25; iou_thres = 0.35
-        classes = [0, 1, 2]; agnostic_nms = True; device = "cuda"; save_path = "./output"
-    det = Detector(Opt)
-    frame = synth.frame_u8(540, 960, seed=11)
+class _Opt:
+    weights = "synthetic:0"; imgsz = 640; augment = True; conf_thres = 0.25; iou_thres = 0.35
+    classes = [0, 1, 2]; agnostic_nms = True; device = "cuda"; save_path = "./output"
+
+
+@pytest.fixture(scope="module")
+def detector():
+    return Detector(_Opt)
+
+
+# 16:9 (384x640 -> 15120 rows), the reference's own sample hamer/example_data/test1.jpg (565x848 -> 448x640, 17640 rows),
+# 4:3 (480x640, 18900), square (640x640, 25200), portrait 1080p (640x384)
+@pytest.mark.parametrize("hw,rows", [((540, 960), 15120), ((565, 848), 17640), ((480, 640), 18900), ((800, 800), 25200),
+                                     ((1920, 1080), 15120)])
+def test_detector_detect_end_to_end(detector, hw, rows):
+    """Detector.detect at every letterbox shape.  With random weights the kept set of a greedy NMS is chaotic under
+    fp16-sized score perturbations, so the end-to-end check is (a) the network output against the oracle in the same
+    arithmetic (emu="fp16") on the SAME letterboxed input, tight, and (b) the box list against the oracle's
+    non_max_suppression + scale_coords applied to the GPU's own prediction, which must agree exactly."""
+    det = detector
+    H, W = hw
+    frame = synth.frame_u8(H, W, seed=11 + H)
     pred, dets_list = det.detect(frame.numpy())
     got = pred[0].cpu()
     assert len(dets_list) == 1 and len(dets_list[0]) == len(got) and got.shape[1] == 6 and len(got) > 0
     assert [lbl for lbl, _ in dets_list[0]] == ['right' if c == 1 else 'left' for c in got[:, 5].tolist()]
-    assert all(0 <= b[0] <= 960 and 0 <= b[1] <= 540 and b[0] == round(b[0]) for _, b in dets_list[0])
-    p = det.engine._plan(540, 960)
+    assert all(0 <= b[0] <= W and 0 <= b[1] <= H and b[0] == round(b[0]) for _, b in dets_list[0])
+    p = det.engine._plan(H, W)
+    assert p["n_pred"] == rows
     gpu_pred = p["pred"].cpu()[None]
-    layers = arch.yolov7_layers()
-    fused = fuse.fuse_state_dict(synth.yolo_state_dict(seed=0, nc=3), arch.conv_specs(layers, 3, 3))
+    layers, fused = _fused()
     with torch.no_grad():
-        ref_dets, ref_list, ref_pred = yolo_ref.detect(layers, fused, frame.numpy(), 3, arch.ANCHORS)
-    assert float((gpu_pred[..., 4:] - ref_pred[..., 4:]).abs().max()) < 2e-2               # (a)
+        ref_dets, ref_list, ref_pred = yolo_ref.detect(layers, fused, frame.numpy(), 3, arch.ANCHORS, emu="fp16")
+    assert float((gpu_pred[..., 4:] - ref_pred[..., 4:]).abs().max()) < 2e-3               # (a)
     mine = yolo_ref.non_max_suppression(gpu_pred, 0.25, 0.35, [0, 1, 2], True)[0]          # (b)
     mine[:, :4] = yolo_ref.scale_coords((p["lp"].out_h, p["lp"].out_w), mine[:, :4], frame.shape).round()
     assert torch.equal(got, mine)
     assert 0.5 * len(ref_dets[0]) <= len(got) <= 2 * len(ref_dets[0]) + 3
+
+
+@pytest.mark.parametrize("n,frac", [(25200, 0.1), (25200, 0.9), (40000, 0.95)])
+def test_nms_many_candidates_exact(n, frac):
+    """hm_yolo_nms takes any row count (general.py:611-703 does): few survivors, more survivors than the in-LDS sort holds
+    (22680 > 16384: sorted in the workspace) and more than max_nms = 30000 (38000: the best 30000 enter the suppression,
+    general.py:679-680); duplicated scores check the tie rule (lower row first).  Exact against the oracle."""
+    lib = L.load()
+    rng = np.random.default_rng(n + int(frac * 100))
+    pred = np.zeros((n, 8), dtype=np.float32)
+    pred[:, 0] = rng.uniform(0, 640, n); pred[:, 1] = rng.uniform(0, 640, n)
+    pred[:, 2] = rng.uniform(8, 60, n); pred[:, 3] = rng.uniform(8, 60, n)
+    keep = rng.uniform(size=n) < frac
+    pred[:, 4] = np.where(keep, rng.uniform(0.5, 1.0, n), rng.uniform(0.0, 0.2, n)).astype(np.float32)
+    pred[:, 5:] = rng.uniform(0.55, 1.0, (n, 3)).astype(np.float32)
+    pred[1::7, 4:] = pred[0:-1:7, 4:][:len(pred[1::7])]                 # equal scores in neighbouring rows
+    pt = torch.from_numpy(pred)
+    ws = torch.empty(lib.hm_nms_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    dets = torch.zeros(300, 6, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    pd = pt.to(DEV)
+    for agnostic, mask in ((1, 0b111), (0, 0b011)):
+        L.check(lib.hm_yolo_nms(pd.data_ptr(), n, 3, 0.25, 0.35, mask, agnostic, 300, None, dets.data_ptr(), count.data_ptr(),
+                                ws.data_ptr(), ws.numel(), L.current_stream()), "hm_yolo_nms")
+        k = int(count.item())
+        ref = yolo_ref.non_max_suppression(pt[None], 0.25, 0.35, [c for c in range(3) if (mask >> c) & 1], bool(agnostic))[0]
+        assert k == len(ref) and torch.equal(dets[:k].cpu(), ref)
+    with pytest.raises(L.HipLibraryError):
+        L.check(lib.hm_yolo_nms(pd.data_ptr(), n, 3, 0.25, 0.35, 7, 1, 300, None, dets.data_ptr(), count.data_ptr(),
+                                ws.data_ptr(), 1024, L.current_stream()), "hm_yolo_nms")          # workspace too small
 
 
 def test_batched_frames_equal_single_frame_passes(engine):

@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 from hamer_yolo_amd import synth
 from hamer_yolo_amd.engine import HamerEngine
 cfg = synth.HamerConfig()
-sd = synth.hamer_state_dict(cfg, seed=0, device="cuda", bf16_representable=True)
+sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
 eng = HamerEngine(sd, synth.mano_params(seed=0), cfg)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 img = synth.normalize_crops(synth.crops_u8(B, seed0=0)).cuda()

@@ -150,10 +150,10 @@ def main():
 
     # ---- tiny geometry: every intermediate
     cfg = synth.tiny_config()
-    sd = synth.hamer_state_dict(cfg, seed=1, bf16_representable=True)
+    sd = synth.hamer_state_dict(cfg, seed=1)          # fp32 master weights, as a real checkpoint holds them (models/__init__.py:46)
     img = synth.normalize_crops(synth.crops_u8(3, seed0=10))
     feats, tok, pose, betas, cam, R = run_reference_hamer(cfg, sd, img, vitmod, ptmod, geo)
-    np.savez_compressed(os.path.join(OUT, "hamer_tiny.npz"), seed=1, crop_seed0=10, bf16_representable=1,
+    np.savez_compressed(os.path.join(OUT, "hamer_tiny.npz"), seed=1, crop_seed0=10, bf16_representable=0,
                         tokens=feats.numpy(), token_out=tok.numpy(), pose6d=pose.numpy(), betas=betas.numpy(),
                         cam=cam.numpy(), rotmats=R.numpy())
     print("tiny: tokens", feats.shape, "pose", pose.shape)
@@ -193,10 +193,10 @@ def main():
 
     if args.full:
         cfg = synth.HamerConfig()
-        sd = synth.hamer_state_dict(cfg, seed=0, bf16_representable=True)
-        img = synth.normalize_crops(synth.crops_u8(2, seed0=0))
+        sd = synth.hamer_state_dict(cfg, seed=0)
+        img = synth.normalize_crops(synth.crops_u8(4, seed0=0))
         feats, tok, pose, betas, cam, R = run_reference_hamer(cfg, sd, img, vitmod, ptmod, geo)
-        np.savez_compressed(os.path.join(OUT, "hamer_vith.npz"), seed=0, crop_seed0=0, bf16_representable=1,
+        np.savez_compressed(os.path.join(OUT, "hamer_vith.npz"), seed=0, crop_seed0=0, bf16_representable=0,
                             tokens_sub=feats[:, ::16, ::40].numpy(), tokens_mean=feats.mean((1, 2)).numpy(),
                             tokens_absmean=feats.abs().mean((1, 2)).numpy(),
                             token_out=tok.numpy(), pose6d=pose.numpy(), betas=betas.numpy(), cam=cam.numpy(),
