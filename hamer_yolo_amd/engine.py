@@ -188,6 +188,7 @@ class HamerEngine:
         """forward() enqueued on ctx.stream (after everything already queued on the caller's current stream, so `img` is
         ready); read ctx.out after ctx.stream.synchronize() or from a stream that waited for it."""
         ctx.stream.wait_stream(torch.cuda.current_stream(self.device))
+        img.record_stream(ctx.stream)          # the caching allocator must not hand `img`'s memory out while ctx.stream still reads it
         with torch.cuda.stream(ctx.stream):
             return self.forward(img, ctx.out, want_tokens=want_tokens, workspace=ctx.workspace)
 

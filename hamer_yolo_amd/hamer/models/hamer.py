@@ -13,6 +13,54 @@ from ...lib import HipLibraryError
 from .mano_wrapper import MANO
 
 
+def engine_config(cfg, state_dict: Dict[str, torch.Tensor]) -> synth.HamerConfig:
+    """The geometry HamerEngine needs, from ``model_config.yaml`` and the checkpoint's own tensor shapes -- and a clear
+    error for every configuration of the reference that the HIP forward does not implement (rather than silently wrong
+    outputs): the reference builds ``vit()`` = ViT-H/16 (backbones/vit.py:343-348), a transformer-decoder head fed the
+    zero token (mano_head.py:31,:86), one IEF iteration (:81) and the 6-D rotation representation (:28-30)."""
+    M = cfg.MODEL
+    head = M.get("MANO_HEAD", {})
+    if str(M.get("BACKBONE", {}).get("TYPE", "vit")) != "vit":
+        raise ValueError(f"unsupported MODEL.BACKBONE.TYPE {M.BACKBONE.TYPE!r}: the HIP forward implements the ViT-H/16 backbone")
+    if str(head.get("TYPE", "transformer_decoder")) != "transformer_decoder":
+        raise ValueError(f"unsupported MODEL.MANO_HEAD.TYPE {head.get('TYPE')!r}")
+    if str(head.get("JOINT_REP", "6d")) != "6d":
+        raise ValueError("unsupported MODEL.MANO_HEAD.JOINT_REP: only the 6-D rotation representation is implemented")
+    if str(head.get("TRANSFORMER_INPUT", "zero")) != "zero":
+        raise ValueError("unsupported MODEL.MANO_HEAD.TRANSFORMER_INPUT: only the zero input token is implemented")
+    if int(head.get("IEF_ITERS", 1)) != 1:
+        raise ValueError("unsupported MODEL.MANO_HEAD.IEF_ITERS: one iteration is implemented (init_* folded into the read-out bias)")
+    if int(cfg.MANO.get("NUM_HAND_JOINTS", 15)) != 15:
+        raise ValueError("MANO.NUM_HAND_JOINTS must be 15")
+    td = dict(head.get("TRANSFORMER_DECODER", {}))
+    if str(td.get("norm", "layer")) != "layer":
+        raise ValueError("unsupported TRANSFORMER_DECODER.norm: only LayerNorm is implemented")
+    sd = state_dict
+    pos = sd["backbone.pos_embed"]
+    D = int(pos.shape[-1])
+    depth = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("backbone.blocks."))
+    pw = sd["backbone.patch_embed.proj.weight"]
+    if D % 80 != 0 or tuple(pw.shape[1:]) != (3, 16, 16) or int(pos.shape[1]) != 193:
+        raise ValueError(f"backbone geometry not supported: pos_embed {tuple(pos.shape)}, patch weight {tuple(pw.shape)} "
+                         "(expected 192+1 tokens of a 256x192 window, 16x16 patches, head_dim 80)")
+    mlp_ratio = int(sd["backbone.blocks.0.mlp.fc1.weight"].shape[0]) // D
+    t = "mano_head.transformer."
+    dim = int(sd[t + "pos_embedding"].shape[-1])
+    ddepth = 1 + max(int(k[len(t):].split(".")[2]) for k in sd if k.startswith(t + "transformer.layers."))
+    inner = int(sd[t + "transformer.layers.0.1.fn.to_q.weight"].shape[0])
+    ctx = int(sd[t + "transformer.layers.0.1.fn.to_kv.weight"].shape[1])
+    dec = synth.DecoderConfig(dim=dim, depth=ddepth, heads=int(td.get("heads", 8)), dim_head=int(td.get("dim_head", 64)),
+                              mlp_dim=int(sd[t + "transformer.layers.0.2.fn.net.0.weight"].shape[0]), context_dim=ctx)
+    if dec.inner != inner or ctx != D or int(td.get("depth", ddepth)) != ddepth or int(td.get("mlp_dim", dec.mlp_dim)) != dec.mlp_dim \
+            or int(td.get("context_dim", ctx)) != ctx or int(td.get("dim", dim)) != dim:
+        raise ValueError("model_config.yaml TRANSFORMER_DECODER does not match the checkpoint's decoder tensors "
+                         f"(config {td}; checkpoint dim {dim}, depth {ddepth}, inner {inner}, mlp {dec.mlp_dim}, context {ctx})")
+    if int(sd[t + "to_token_embedding.weight"].shape[1]) != 1 or int(sd["mano_head.decpose.weight"].shape[0]) != 96:
+        raise ValueError("decoder input token / pose read-out shape not supported (zero token of width 1, 96 = 16 x 6-D rotations)")
+    vit = synth.ViTConfig(embed_dim=D, depth=depth, heads=D // 80, mlp_ratio=mlp_ratio)
+    return synth.HamerConfig(vit=vit, dec=dec, image_size=int(M.IMAGE_SIZE), focal_length=float(cfg.EXTRA.FOCAL_LENGTH))
+
+
 class HAMER:
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], mano: MANO, dtype=torch.float16,
                  hamer_cfg: Optional[synth.HamerConfig] = None):
@@ -20,7 +68,7 @@ class HAMER:
         self.mano = mano
         self.dtype = dtype
         self._sd = state_dict
-        self._hc = hamer_cfg or synth.HamerConfig(image_size=int(cfg.MODEL.IMAGE_SIZE), focal_length=float(cfg.EXTRA.FOCAL_LENGTH))
+        self._hc = hamer_cfg or engine_config(cfg, state_dict)
         self._engine: Optional[HamerEngine] = None
         self.device = torch.device("cpu")
         self.training = False

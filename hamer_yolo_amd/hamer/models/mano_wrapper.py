@@ -30,15 +30,27 @@ class _Stub:
 
 
 class _RestrictedUnpickler(pickle.Unpickler):
-    _ALLOWED = ("numpy", "scipy.sparse")
+    """Exact (module, name) allow-list for the MANO pickle: numpy array reconstruction and scipy's CSC matrix (the joint
+    regressor); chumpy wrappers become ``_Stub``; anything else is refused (no prefix matching: numpy and scipy expose
+    helpers that evaluate strings)."""
 
     def find_class(self, module, name):
-        if module.startswith("chumpy"):
+        if module.startswith("chumpy."):
             return _Stub
-        if module.split(".")[0] in ("numpy", "scipy") or module.startswith("scipy.sparse"):
-            return super().find_class(module, name)
+        if (module, name) in (("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct")):
+            return (getattr(np, "_core", None) or np.core).multiarray._reconstruct
+        if (module, name) == ("numpy", "ndarray"):
+            return np.ndarray
+        if (module, name) == ("numpy", "dtype"):
+            return np.dtype
+        if name in ("csc_matrix", "csr_matrix", "coo_matrix") and module in ("scipy.sparse.csc", "scipy.sparse._csc", "scipy.sparse.csr",
+                                                                             "scipy.sparse._csr", "scipy.sparse.coo", "scipy.sparse._coo"):
+            import scipy.sparse
+            return getattr(scipy.sparse, name)
         if module in ("__builtin__", "builtins") and name in ("set", "frozenset", "list", "dict", "tuple"):
             return {"set": set, "frozenset": frozenset, "list": list, "dict": dict, "tuple": tuple}[name]
+        if (module, name) in (("_codecs", "encode"), ("copy_reg", "_reconstructor"), ("copyreg", "_reconstructor")):
+            return super().find_class(module, name)
         raise pickle.UnpicklingError(f"MANO pickle: refusing global {module}.{name}")
 
 

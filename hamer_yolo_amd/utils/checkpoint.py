@@ -4,8 +4,9 @@
 experimental.py:260-283, which needs ``models.yolo.Model`` & co. importable), and a Lightning ``hamer.ckpt`` may
 carry ``yacs`` / ``pytorch_lightning`` objects beside its ``state_dict``.  Neither package tree exists here, and
 unpickling arbitrary globals is unsafe anyway, so ``load_checkpoint`` runs ``torch.load`` with an unpickler that
-  * lets through tensors, storages, containers and numpy arrays (an allow-list), and
-  * turns every other class into an inert attribute bag (``Stub``) -- no foreign code runs.
+  * lets through tensors, storages, containers and numpy arrays (an allow-list of exact (module, name) pairs), and
+  * turns every other global into an inert attribute bag (``Stub``): a pickled ``os.system`` / ``eval`` / import helper is
+    never resolved, so calling it (REDUCE) only builds another ``Stub``.
 ``module_state_dict`` then walks a stubbed module tree (``_parameters`` / ``_buffers`` / ``_modules``) and
 returns what ``module.state_dict()`` would have.
 """
@@ -17,13 +18,31 @@ from typing import Any, Dict
 
 import torch
 
-_ALLOWED_PREFIXES = ("torch._utils", "torch.storage", "torch._tensor", "torch.serialization", "collections", "numpy")
+# Exact (module, name) pairs that are resolved to the real object: constructors of tensors, storages, containers and
+# numpy arrays -- nothing that imports, evaluates or calls through a name taken from the pickle.  (A module-PREFIX
+# allow-list is not enough: ``torch._utils._import_dotted_name`` or ``numpy.testing._private.utils.runstring`` would be
+# reachable through it.)  Everything else becomes an inert ``Stub``.
+_TORCH_DTYPES = {n for n in dir(torch) if isinstance(getattr(torch, n, None), torch.dtype)}
 _ALLOWED_EXACT = {
-    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
-    ("copyreg", "_reconstructor"), ("builtins", "object"), ("builtins", "set"), ("builtins", "frozenset"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"), ("builtins", "object"), ("builtins", "set"), ("builtins", "frozenset"),
     ("builtins", "slice"), ("builtins", "range"), ("builtins", "complex"), ("builtins", "bytearray"),
-    ("_codecs", "encode"), ("__builtin__", "object"), ("__builtin__", "set"),
+    ("_codecs", "encode"), ("__builtin__", "object"), ("__builtin__", "set"), ("__builtin__", "frozenset"),
 }
+
+
+def _allowed(module: str, name: str) -> bool:
+    if (module, name) in _ALLOWED_EXACT:
+        return True
+    if module == "torch" and (name in _TORCH_DTYPES or (name.endswith("Storage") and name[:-7].isalpha())):
+        return True                                 # torch.float32, torch.FloatStorage, ...: plain classes / dtype singletons
+    return False
 
 
 class Stub:
@@ -77,7 +96,7 @@ def _stub_class(module: str, name: str) -> type:
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if (module, name) in _ALLOWED_EXACT or module.startswith(_ALLOWED_PREFIXES) or (module == "torch" and name.endswith("Storage")):
+        if _allowed(module, name):
             return super().find_class(module, name)
         return _stub_class(module, name)
 

@@ -33,20 +33,25 @@ def checkpoint_state_dict(ck):
 
 
 def attempt_load(weights: str):
-    """experimental.py:260-283 equivalent: returns an UNFUSED state dict (BN / RepConv / implicit folding happens in
-    YoloEngine, fuse.py).  ``"synthetic:<seed>"`` draws seeded random-init weights; a file is read with the class-free
+    """experimental.py:260-283 equivalent: returns (UNFUSED state dict, nc, class names) -- BN / RepConv / implicit folding
+    happens in YoloEngine (fuse.py); the detect head's ``anchor_grid`` buffer stays in the state dict and is what the decode
+    uses.  ``"synthetic:<seed>"`` draws seeded random-init weights; a file is read with the class-free
     unpickler (utils/checkpoint.py), so the reference's own ``yolov7_best.pt`` loads without its ``models`` package."""
     weights = str(weights)
     if weights.startswith("synthetic"):
         seed = int(weights.split(":")[1]) if ":" in weights else 0
-        return synth.yolo_state_dict(seed=seed, nc=3), 3
+        return synth.yolo_state_dict(seed=seed, nc=3), 3, ['0', '1', '2']
     from ..utils.checkpoint import load_checkpoint
-    sd = checkpoint_state_dict(load_checkpoint(weights))               # FileNotFoundError when missing
+    ck = load_checkpoint(weights)                                      # FileNotFoundError when missing
+    sd = checkpoint_state_dict(ck)
     det = [k for k in sd if k.endswith(".m.0.weight")]
     if not det:
         raise TypeError("YOLOv7 checkpoint without a detect head (no '*.m.0.weight')")
     nc = sd[det[0]].shape[0] // 3 - 5
-    return sd, nc
+    mod = (ck.get("ema") or ck.get("model")) if isinstance(ck, dict) else ck
+    names = getattr(mod, "names", None)                                # Model.names (yolo.py:533), read at detector.py:157
+    names = [str(n) for n in names] if isinstance(names, (list, tuple)) and len(names) == nc else [str(i) for i in range(nc)]
+    return sd, nc, names
 
 
 class _Model:
@@ -64,10 +69,10 @@ class Detector():
         self.device = torch.device(self.device if torch.cuda.is_available() else 'cpu')
         if self.device.type != 'cuda':
             raise L.HipLibraryError("Detector runs on an MI355X only: the HIP hot path has no CPU fallback")
-        sd, nc = attempt_load(weights)
+        sd, nc, names = attempt_load(weights)
         stride = 32
         self.imgsz = int(np.ceil(imgsz / stride) * stride)               # check_img_size, general.py:126-131
-        self.engine = YoloEngine(sd, nc=nc, device=self.device, new_shape=self.imgsz, stride=stride)
+        self.engine = YoloEngine(sd, nc=nc, device=self.device, new_shape=self.imgsz, stride=stride, names=names)
         self.model = _Model(self.engine)
         self.opt = config
         self.detect_savepath = config.save_path

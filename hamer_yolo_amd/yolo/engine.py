@@ -23,9 +23,28 @@ def _kpad(k: int) -> int:
     return (k + 63) // 64 * 64
 
 
+def detect_anchors(state_dict: Dict[str, torch.Tensor]) -> List[List[float]]:
+    """Anchor sizes in pixels per detect level, [3][w0, h0, w1, h1, w2, h2].  IDetect decodes with its ``anchor_grid``
+    buffer (yolo.py:164), which travels in the checkpoint and may have been rewritten by autoanchor for a custom-trained
+    detector, so the checkpoint's values win: ``*.anchor_grid`` (pixels), else ``*.anchors`` (in stride units, yolo.py:
+    537-539) times the strides, else the yolov7.yaml defaults."""
+    grid = [v for k, v in state_dict.items() if k.endswith(".anchor_grid")]
+    unit = [v for k, v in state_dict.items() if k.endswith(".anchors")]
+    if grid:
+        a = grid[0].detach().float().cpu().reshape(-1, 6)
+    elif unit:
+        a = unit[0].detach().float().cpu().reshape(-1, 3, 2) * torch.tensor(arch.STRIDES, dtype=torch.float32).view(-1, 1, 1)
+        a = a.reshape(-1, 6)
+    else:
+        return [[float(v) for v in lvl] for lvl in arch.ANCHORS]
+    if a.shape != (len(arch.STRIDES), 6) or not bool(torch.isfinite(a).all()) or not bool((a > 0).all()):
+        raise ValueError(f"detect head anchors: expected {len(arch.STRIDES)} levels x 3 positive (w, h) pairs, got shape {tuple(a.shape)}")
+    return [[float(v) for v in lvl] for lvl in a]
+
+
 class YoloEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], nc: int = 3, device="cuda", dtype=torch.float16,
-                 new_shape: int = 640, stride: int = 32):
+                 new_shape: int = 640, stride: int = 32, names: Optional[List[str]] = None):
         if not torch.cuda.is_available():
             raise L.HipLibraryError("YoloEngine needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = L.load()
@@ -47,7 +66,8 @@ class YoloEngine:
             flat[:, :k * k * cin] = wk.reshape(co, -1)
             self.w[name] = (flat.to(self.device, dtype).contiguous(), b.to(self.device, torch.float32).contiguous(), cin, k, s, co)
         self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
-        self.names = ['0', '1', '2']                         # class names live in the checkpoint (detector.py:157)
+        self.anchors = detect_anchors(state_dict)            # pixels, per level: the checkpoint's anchor_grid (yolo.py:164)
+        self.names = list(names) if names is not None else [str(i) for i in range(nc)]   # Model.names of the checkpoint
         self._plans: Dict[Tuple[int, int], dict] = {}
 
     # ------------------------------------------------------------------ planning
@@ -217,7 +237,7 @@ class YoloEngine:
         for i in range(p["nb"]):
             row0 = i * p["n_pred"]
             for l, (raw, hh, ww) in enumerate(p["raws"]):
-                anc = (C.c_float * 6)(*[float(v) for v in arch.ANCHORS[l]])
+                anc = (C.c_float * 6)(*self.anchors[l])
                 L.check(self.lib.hm_yolo_decode(raw.data_ptr() + i * hh * ww * 3 * self.no * 4, 3 * self.no, p["pred"].data_ptr(), row0,
                                                 hh, ww, self.nc, float(arch.STRIDES[l]), anc, st), "hm_yolo_decode")
                 row0 += 3 * hh * ww

@@ -88,6 +88,35 @@ def _conv(x: Tensor, wb: Tuple[Tensor, Tensor], k: int, s: int, act: bool = True
     return y if out_f32 else _h(y, emu)
 
 
+def layer_forward(layers, fused: Dict[str, Tuple[Tensor, Tensor]], i: int, inp: List[Tensor], nc: int = 3, emu=False):
+    """One layer of Model.forward_once (yolo.py:609-639) on explicit inputs (what the layer's sources produced).  The detect
+    layer returns its three raw maps (B, 3, ny, nx, 5+nc) before the sigmoid."""
+    _, kind, args = layers[i]
+    if kind == "conv":
+        return _conv(inp[0], fused[f"model.{i}.conv"], args[1], args[2], emu=emu)
+    if kind == "repconv":
+        return _conv(inp[0], fused[f"model.{i}.rbr_reparam"], 3, 1, emu=emu)
+    if kind == "mp":
+        return F.max_pool2d(inp[0], 2, 2)
+    if kind == "up":
+        return F.interpolate(inp[0], scale_factor=2, mode="nearest")
+    if kind == "concat":
+        return torch.cat(inp, 1)
+    if kind == "sppcspc":                                        # common.py:279-284
+        cv = lambda j, t, k: _conv(t, fused[f"model.{i}.cv{j}.conv"], k, 1, emu=emu)
+        x1 = cv(4, cv(3, cv(1, inp[0], 1), 3), 1)
+        y1 = cv(6, cv(5, torch.cat([x1] + [F.max_pool2d(x1, k, 1, k // 2) for k in (5, 9, 13)], 1), 1), 3)
+        return cv(7, torch.cat((y1, cv(2, inp[0], 1)), dim=1), 1)
+    if kind == "detect":
+        raws, no = [], nc + 5
+        for l, t in enumerate(inp):
+            r = _conv(t, fused[f"model.{i}.m.{l}"], 1, 1, act=False, emu=emu, out_f32=True)
+            bs, _, ny, nx = r.shape
+            raws.append(r.view(bs, 3, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous())
+        return raws
+    raise ValueError(kind)
+
+
 def yolo_forward(layers, fused: Dict[str, Tuple[Tensor, Tensor]], x: Tensor, nc: int = 3,
                  anchors: Sequence[Sequence[int]] = (), strides: Sequence[int] = (8, 16, 32), emu=False) -> Tuple[Tensor, List[Tensor]]:
     """Model.forward_once over the fused graph (yolo.py:609-639) + IDetect.fuseforward (yolo.py:148-184).
@@ -99,29 +128,11 @@ def yolo_forward(layers, fused: Dict[str, Tuple[Tensor, Tensor]], x: Tensor, nc:
     for i, (frm, kind, args) in enumerate(layers):
         srcs = frm if isinstance(frm, list) else [frm]
         inp = [x if (s == -1 and i == 0) else ys[s if s >= 0 else i + s] for s in srcs]
-        if kind == "conv":
-            y = _conv(inp[0], fused[f"model.{i}.conv"], args[1], args[2], emu=emu)
-        elif kind == "repconv":
-            y = _conv(inp[0], fused[f"model.{i}.rbr_reparam"], 3, 1, emu=emu)
-        elif kind == "mp":
-            y = F.max_pool2d(inp[0], 2, 2)
-        elif kind == "up":
-            y = F.interpolate(inp[0], scale_factor=2, mode="nearest")
-        elif kind == "concat":
-            y = torch.cat(inp, 1)
-        elif kind == "sppcspc":                                  # common.py:279-284
-            cv = lambda j, t, k: _conv(t, fused[f"model.{i}.cv{j}.conv"], k, 1, emu=emu)
-            x1 = cv(4, cv(3, cv(1, inp[0], 1), 3), 1)
-            y1 = cv(6, cv(5, torch.cat([x1] + [F.max_pool2d(x1, k, 1, k // 2) for k in (5, 9, 13)], 1), 1), 3)
-            y = cv(7, torch.cat((y1, cv(2, inp[0], 1)), dim=1), 1)
-        elif kind == "detect":
-            z, raws = [], []
-            no = nc + 5
-            for l, t in enumerate(inp):
-                r = _conv(t, fused[f"model.{i}.m.{l}"], 1, 1, act=False, emu=emu, out_f32=True)
-                bs, _, ny, nx = r.shape
-                r = r.view(bs, 3, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
-                raws.append(r)
+        y = layer_forward(layers, fused, i, inp, nc, emu)
+        if kind == "detect":
+            z, no = [], nc + 5
+            for l, r in enumerate(y):
+                bs, _, ny, nx, _ = r.shape
                 yv, xv = torch.meshgrid([torch.arange(ny), torch.arange(nx)], indexing="ij")
                 grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2).float()
                 ag = torch.tensor(anchors[l]).float().view(1, 3, 1, 1, 2)
@@ -129,7 +140,7 @@ def yolo_forward(layers, fused: Dict[str, Tuple[Tensor, Tensor]], x: Tensor, nc:
                 yy[..., 0:2] = (yy[..., 0:2] * 2. - 0.5 + grid) * strides[l]
                 yy[..., 2:4] = (yy[..., 2:4] * 2) ** 2 * ag
                 z.append(yy.view(bs, -1, no))
-            return torch.cat(z, 1), raws
+            return torch.cat(z, 1), y
         ys.append(y)
     raise ValueError("graph has no detect layer")
 

@@ -120,11 +120,52 @@ def _fused():
     return layers, fuse.fuse_state_dict(synth.yolo_state_dict(seed=0, nc=3), arch.conv_specs(layers, 3, 3))
 
 
+def test_every_layer_vs_oracle_on_the_gpus_own_inputs(engine):
+    """Teacher-forced, layer by layer: each of the 105 layers + the detect head is recomputed by the oracle (emu="fp16": half
+    weights / activations, fp32 accumulate -- the reference's GPU branch, detector.py:110-112) FROM THE GPU'S OWN INPUT
+    TENSORS of that layer and compared with the GPU's output of that layer.  What is left between the two is the fp32
+    summation order inside ONE layer: a result differs by at most one or two half ulps, and almost every element is
+    bit-equal.  Pooling, upsampling and the concat-by-addressing must be exact.  (End to end the same noise random-walks
+    through 105 layers of |x| <= 15 activations to ~2e-3 mean / 6e-2 max on the logits -- the floor for ANY two half
+    implementations with different summation orders -- so the whole-network bounds below are necessarily looser.)"""
+    frame = synth.frame_u8(540, 960, seed=5)
+    p = engine.forward(frame.to(DEV))
+    torch.cuda.synchronize()
+    layers, fused = _fused()
+    lp = p["lp"]
+    off = p["img_ptr"] - p["arena"].data_ptr()
+    x8 = p["arena"][off:off + lp.out_h * lp.out_w * 16].view(torch.float16).reshape(lp.out_h, lp.out_w, 8).cpu().float()
+    img = x8[..., :3].permute(2, 0, 1)[None].contiguous()
+    outs = {}
+    get = lambda j: outs.setdefault(j, engine.layer_output(p, j)[None])
+    n_conv = 0
+    with torch.no_grad():
+        for i, (srcs, kind, args) in enumerate(arch.resolve(layers)):
+            inp = [img if s < 0 else get(s) for s in srcs]
+            ref = yolo_ref.layer_forward(layers, fused, i, inp, 3, emu="fp16")
+            if kind == "detect":
+                for (raw, hh, ww), r in zip(p["raws"], ref):
+                    mine = raw.cpu().reshape(hh, ww, 3, 8).permute(2, 0, 1, 3)
+                    np.testing.assert_allclose(mine.numpy(), r[0].numpy(), rtol=1e-4, atol=2e-4, err_msg=f"detect level {hh}x{ww}")
+                continue
+            got = get(i)
+            assert got.shape == ref.shape, (i, kind, got.shape, ref.shape)
+            if kind in ("mp", "up", "concat"):
+                assert torch.equal(got, ref), (i, kind)
+                continue
+            n_conv += 1
+            k = 4.0 if kind == "sppcspc" else 1.0                       # 7 chained convolutions inside SPPCSPC
+            bad = (got - ref).abs() > k * (2.0 ** -9 * ref.abs() + 1e-3)
+            same = float((got == ref).float().mean())
+            assert not bool(bad.any()), (i, kind, int(bad.sum()), float((got - ref).abs().max()))
+            assert same > (0.6 if kind == "sppcspc" else 0.97), (i, kind, same)
+    assert n_conv == 79 + 3 + 1
+
+
 def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
-    """Whole network, two bounds.  TIGHT: against the oracle in the kernel's own arithmetic (``emu="fp16"``: half weights
-    and activations, fp32 accumulate -- what the reference's GPU branch computes, detector.py:110-112): raw head logits within
-    1e-2, scores within 2e-3 -- an indexing slip in any of the 92 convolutions cannot pass that.  LOOSE: against the fp32
-    reference golden (fp16 rounding noise through 105 layers of |x| <= 15 activations)."""
+    """Whole network on the reference's golden input.  Against the oracle in the kernel's own arithmetic (emu="fp16") the
+    raw head logits agree to the half-precision reordering floor (see the per-layer test: mean ~2e-3, max ~6e-2) and the
+    scores to 1e-2; against the fp32 reference golden the bounds are those of half vs single precision."""
     g = np.load(os.path.join(golden_dir, "yolo_forward.npz"))
     # the golden input is this image taken as RGB; the detector takes BGR frames (cv2.imread order) and the
     # letterbox kernel swaps to RGB, so hand it the channel-reversed frame.  384x640: the resize is the identity.
@@ -141,12 +182,12 @@ def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
     for (raw, hh, ww), r, r32 in zip(p["raws"], eraws, raws):                # r: (1, 3, ny, nx, 8)
         mine = raw.cpu().reshape(hh, ww, 3, 8).permute(2, 0, 1, 3)
         d = (mine - r[0]).abs()
-        assert float(d.max()) < 1e-2 and float(d.mean()) < 5e-4, (float(d.max()), float(d.mean()))
+        assert float(d.max()) < 0.1 and float(d.mean()) < 4e-3, (float(d.max()), float(d.mean()))
         d32 = (mine - r32[0]).abs()
         assert float(d32.max()) < 0.3 and float(d32.mean()) < 0.02
-    assert float((pred[:, 4:] - epred[0, :, 4:]).abs().max()) < 2e-3
+    assert float((pred[:, 4:] - epred[0, :, 4:]).abs().max()) < 1e-2
     size = epred[0, :, 2:4].abs().mean(1, keepdim=True).clamp_min(8.0)
-    assert float(((pred[:, :4] - epred[0, :, :4]).abs() / size).max()) < 1e-2
+    assert float(((pred[:, :4] - epred[0, :, :4]).abs() / size).max()) < 5e-2
     # loose: the reference's own fp32 output rows
     ref_rows = torch.from_numpy(g["pred_rows"])
     got = pred[::9]
@@ -212,7 +253,7 @@ def test_detector_detect_end_to_end(detector, hw, rows):
     layers, fused = _fused()
     with torch.no_grad():
         ref_dets, ref_list, ref_pred = yolo_ref.detect(layers, fused, frame.numpy(), 3, arch.ANCHORS, emu="fp16")
-    assert float((gpu_pred[..., 4:] - ref_pred[..., 4:]).abs().max()) < 2e-3               # (a)
+    assert float((gpu_pred[..., 4:] - ref_pred[..., 4:]).abs().max()) < 1e-2               # (a) (the half reordering floor)
     mine = yolo_ref.non_max_suppression(gpu_pred, 0.25, 0.35, [0, 1, 2], True)[0]          # (b)
     mine[:, :4] = yolo_ref.scale_coords((p["lp"].out_h, p["lp"].out_w), mine[:, :4], frame.shape).round()
     assert torch.equal(got, mine)

@@ -262,3 +262,99 @@ def test_rootnet_bbox_and_k_known_answers():
     np.testing.assert_allclose(sanitize_bbox([-20.0, 400.0, 100.0, 200.0], 640, 480), [0, 400, 99, 79])
     # k = sqrt(0.3 * 0.3 * fx * fy / (w * h)): fx = fy = 1000, 150 px square -> 0.3 * 1000 / 150 = 2
     assert abs(RR.calculate_k([0, 0, 150.0, 150.0], 1000.0, 1000.0) - 2.0) < 1e-6
+
+
+def test_unpicklers_never_resolve_code_execution_gadgets(tmp_path):
+    """Both checkpoint readers work from exact (module, name) allow-lists.  Pickles that reach for os.system, builtins.eval,
+    torch._utils._import_dotted_name (an import-by-name helper inside an otherwise trusted module) or numpy's runstring must
+    load as inert stubs / be refused, and nothing they name may run."""
+    import io
+    import pickle
+    import zipfile
+    import torch
+    from hamer_yolo_amd.hamer.models.mano_wrapper import _RestrictedUnpickler
+    from hamer_yolo_amd.utils.checkpoint import Stub, _Unpickler, load_checkpoint
+    marker = tmp_path / "pwned"
+
+    def gadget(module, name, *args):
+        """GLOBAL module name; args...; REDUCE -- what ``__reduce__`` returning (callable, args) pickles to."""
+        out = io.BytesIO()
+        out.write(b"\x80\x02c" + module.encode() + b"\n" + name.encode() + b"\n")
+        out.write(pickle.dumps(tuple(args), protocol=2)[2:-1])      # the args tuple without PROTO / STOP
+        out.write(b"R.")
+        return out.getvalue()
+
+    payloads = [
+        gadget("os", "system", f"touch {marker}"),
+        gadget("posix", "system", f"touch {marker}"),
+        gadget("builtins", "eval", f"open({str(marker)!r}, 'w').close()"),
+        gadget("builtins", "exec", f"open({str(marker)!r}, 'w').close()"),
+        gadget("torch._utils", "_import_dotted_name", "os.system"),
+        gadget("numpy.testing._private.utils", "runstring", f"open({str(marker)!r}, 'w').close()", {}),
+        gadget("numpy_x", "anything", 1),
+        gadget("collectionsfoo", "OrderedDict"),
+        gadget("torch.storage", "_load_from_bytes", b"\x80\x02N."),
+    ]
+    for raw in payloads:
+        obj = _Unpickler(io.BytesIO(raw)).load()
+        assert isinstance(obj, Stub), raw
+        with pytest.raises(pickle.UnpicklingError):
+            _RestrictedUnpickler(io.BytesIO(raw), encoding="latin1").load()
+    # two-step gadget: resolve os.system through the import helper, then call it
+    two = (b"\x80\x02ctorch._utils\n_import_dotted_name\n" + pickle.dumps(("os.system",), protocol=2)[2:-1] + b"R"
+           + pickle.dumps((f"touch {marker}",), protocol=2)[2:-1] + b"R.")
+    assert isinstance(_Unpickler(io.BytesIO(two)).load(), Stub)
+    # the same through torch.load's zip container
+    path = str(tmp_path / "evil.pt")
+    torch.save({"state_dict": {"w": torch.ones(2)}}, path)
+    with zipfile.ZipFile(path) as zin, zipfile.ZipFile(str(tmp_path / "evil2.pt"), "w") as zout:
+        for item in zin.infolist():
+            data = zin.read(item.filename)
+            if item.filename.endswith("data.pkl"):
+                data = payloads[0]
+            zout.writestr(item, data)
+    assert isinstance(load_checkpoint(str(tmp_path / "evil2.pt")), Stub)
+    assert not marker.exists()
+
+
+def test_engine_config_follows_checkpoint_and_rejects_unsupported_heads():
+    """HAMER derives the engine geometry from model_config.yaml + the checkpoint's tensor shapes: a config the HIP
+    forward does not implement must raise, not produce silently wrong outputs (mano_head.py:28-31,:81,:86)."""
+    from hamer_yolo_amd.hamer.configs import get_config
+    from hamer_yolo_amd.hamer.models.hamer import engine_config
+    tiny = synth.tiny_config()
+    sd = synth.hamer_state_dict(tiny, seed=0)
+    cfg = get_config(None)
+    with pytest.raises(ValueError, match="does not match the checkpoint"):
+        engine_config(cfg, sd)                                   # default yaml says depth 6 / dim 1024, the tensors say 2 / 256
+    cfg.MODEL.MANO_HEAD.TRANSFORMER_DECODER.merge({"depth": 2, "heads": 4, "mlp_dim": 256, "dim_head": 64, "context_dim": 320, "dim": 256})
+    assert engine_config(cfg, sd) == tiny
+    for key, val in (("TRANSFORMER_INPUT", "mean_shape"), ("IEF_ITERS", 3), ("JOINT_REP", "aa"), ("TYPE", "mlp")):
+        bad = get_config(None)
+        bad.MODEL.MANO_HEAD.TRANSFORMER_DECODER.merge({"depth": 2, "heads": 4, "mlp_dim": 256, "context_dim": 320, "dim": 256})
+        bad.MODEL.MANO_HEAD[key] = val
+        with pytest.raises(ValueError, match="unsupported"):
+            engine_config(bad, sd)
+    bad = get_config(None)
+    bad.MODEL.BACKBONE.TYPE = "resnet"
+    with pytest.raises(ValueError, match="BACKBONE"):
+        engine_config(bad, sd)
+
+
+def test_detect_anchors_come_from_the_checkpoint(golden_dir):
+    """IDetect decodes with its anchor_grid buffer (yolo.py:164); autoanchor may have rewritten it for a custom detector."""
+    import os
+    from hamer_yolo_amd.utils.checkpoint import load_checkpoint
+    from hamer_yolo_amd.yolo import arch
+    from hamer_yolo_amd.yolo.detector import attempt_load, checkpoint_state_dict
+    from hamer_yolo_amd.yolo.engine import detect_anchors
+    assert detect_anchors({}) == [[float(v) for v in l] for l in arch.ANCHORS]
+    grid = torch.tensor([[10., 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]])
+    assert detect_anchors({"model.105.anchor_grid": grid.view(3, 1, 3, 1, 1, 2)}) == grid.tolist()
+    unit = grid.view(3, 3, 2) / torch.tensor([8., 16, 32]).view(3, 1, 1)
+    assert detect_anchors({"model.105.anchors": unit}) == grid.tolist()
+    with pytest.raises(ValueError):
+        detect_anchors({"model.105.anchor_grid": torch.zeros(2, 1, 3, 1, 1, 2)})
+    sd, nc, names = attempt_load(os.path.join(golden_dir, "yolo_tiny_ckpt.pt"))
+    assert nc == 3 and names == ["left", "right", "other"]
+    assert detect_anchors(sd) == [[12.0, 16.0, 19.0, 36.0, 40.0, 28.0], [36.0, 75.0, 76.0, 55.0, 72.0, 146.0], [142.0, 110.0, 192.0, 243.0, 459.0, 401.0]]
