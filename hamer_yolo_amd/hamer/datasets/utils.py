@@ -5,21 +5,16 @@ import numpy as np
 
 
 def expand_to_aspect_ratio(input_shape, target_aspect_ratio=None):
-    """datasets/utils.py:15-34."""
+    """Smallest (w, h) >= input with w : h = target (reference behaviour: datasets/utils.py:15-34): each side is raised to
+    what the other side demands at the target ratio -- exactly one of the two grows.  Anything that is not a (w, h) pair is
+    returned unchanged, as is the input when no target is given."""
     if target_aspect_ratio is None:
         return input_shape
-    try:
-        w, h = input_shape
-    except (ValueError, TypeError):
+    wh = np.asarray(input_shape, dtype=np.float64)
+    if wh.shape != (2,):
         return input_shape
-    w_t, h_t = target_aspect_ratio
-    if h / w < h_t / w_t:
-        h_new = max(w * h_t / w_t, h)
-        w_new = w
-    else:
-        h_new = h
-        w_new = max(h * w_t / h_t, w)
-    return np.array([w_new, h_new])
+    tw, th = target_aspect_ratio
+    return np.maximum(wh, np.array([wh[1] * tw / th, wh[0] * th / tw]))
 
 
 def gen_trans_from_patch_cv(c_x, c_y, src_width, src_height, dst_width, dst_height, scale=1.0, rot=0.0):

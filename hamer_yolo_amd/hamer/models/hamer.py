@@ -70,6 +70,7 @@ class HAMER:
         self._sd = state_dict
         self._hc = hamer_cfg or engine_config(cfg, state_dict)
         self._engine: Optional[HamerEngine] = None
+        self._ws = {}                  # HIP stream -> (capacity in hands, workspace): forwards on different streams may overlap
         self.device = torch.device("cpu")
         self.training = False
 
@@ -83,6 +84,19 @@ class HAMER:
             self.device = device
         return self
 
+    def _workspace(self, B: int) -> torch.Tensor:
+        """The forward's scratch memory, one per HIP stream the model is called on (batches issued on different streams
+        overlap on the GPU and must not share scratch); grown in steps of 64 hands."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        cap, ws = self._ws.get(key, (0, None))
+        if cap < B:
+            cap = (B + 63) // 64 * 64
+            import ctypes as C
+            n = self._engine.lib.hm_hamer_workspace_bytes(C.byref(self._engine.w), cap)
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws[key] = (cap, ws)
+        return ws
+
     def eval(self):
         self.training = False
         return self
@@ -92,7 +106,7 @@ class HAMER:
             raise HipLibraryError("call model.to('cuda') before the first forward")
         x = batch["img"]
         B = x.shape[0]
-        o = self._engine.forward(x.to(self.device, torch.float32))
+        o = self._engine.forward(x.to(self.device, torch.float32), workspace=self._workspace(B))
         R = o["rotmats"]
         pred_mano_params = {"global_orient": R[:, :1], "hand_pose": R[:, 1:], "betas": o["betas"]}
         output = {

@@ -7,13 +7,14 @@ import torch
 
 
 def rot6d_to_rotmat(x: torch.Tensor) -> torch.Tensor:
-    """geometry.py:47-70."""
-    x = x.reshape(-1, 2, 3).permute(0, 2, 1).contiguous()
-    a1, a2 = x[:, :, 0], x[:, :, 1]
-    b1 = torch.nn.functional.normalize(a1)
-    b2 = torch.nn.functional.normalize(a2 - torch.einsum("bi,bi->b", b1, a2).unsqueeze(-1) * b1)
-    b3 = torch.linalg.cross(b1, b2, dim=1)
-    return torch.stack((b1, b2, b3), dim=-1)
+    """6-D rotation representation -> rotation matrices (reference behaviour: geometry.py:47-70, the same Gram-Schmidt as
+    the fused HIP MANO kernel): the first three numbers are the first COLUMN direction, the next three the second; columns
+    (b1, b2, b1 x b2), norms floored at 1e-12."""
+    a1, a2 = x.reshape(-1, 2, 3).unbind(dim=1)
+    b1 = a1 / a1.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    u = a2 - (b1 * a2).sum(dim=1, keepdim=True) * b1
+    b2 = u / u.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    return torch.stack((b1, b2, torch.linalg.cross(b1, b2, dim=1)), dim=-1)
 
 
 def perspective_projection(points: torch.Tensor, translation: torch.Tensor, focal_length: torch.Tensor,

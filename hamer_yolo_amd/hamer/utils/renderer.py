@@ -1,45 +1,37 @@
-"""Camera maths of the reference's renderer module (hamer/hamer/utils/renderer.py:12-74).  The
-pyrender/trimesh renderer classes themselves are visualisation and out of scope."""
+"""Crop camera -> full-image camera (reference behaviour: hamer/hamer/utils/renderer.py:12-74 ``cam_crop_to_full`` /
+``custom_cam_crop_to_full``).  The weak-perspective camera (s, tx, ty) predicted on the crop is moved into the frame of
+the full image: with ``bs = S * s`` the size of the hand box in focal-normalised units, depth is ``2 fx / bs`` and the
+principal-point offset of the box centre adds ``2 (c_box - c) / bs``.  The pyrender/trimesh renderer classes of that module
+are visualisation and out of scope."""
 import torch
 
 
-def cam_crop_to_full(cam_bbox, box_center, box_size, img_size, focal_length=5000.):
-    """renderer.py:12-22."""
-    img_w, img_h = img_size[:, 0], img_size[:, 1]
-    cx, cy, b = box_center[:, 0], box_center[:, 1], box_size
-    w_2, h_2 = img_w / 2., img_h / 2.
-    bs = b * cam_bbox[:, 0] + 1e-9
-    tz = 2 * focal_length / bs
-    tx = (2 * (cx - w_2) / bs) + cam_bbox[:, 1]
-    ty = (2 * (cy - h_2) / bs) + cam_bbox[:, 2]
-    return torch.stack([tx, ty, tz], dim=-1)
+def _per_hand(value, n: int, like: torch.Tensor) -> torch.Tensor:
+    """Scalar, 0-d / 1-element tensor, sequence or (n,) tensor -> float32 (n,) on ``like``'s device."""
+    t = torch.as_tensor(value, device=like.device).to(torch.float32).reshape(-1)
+    return t.expand(n) if t.numel() == 1 else t
 
 
 def custom_cam_crop_to_full(cam_bbox, box_center, box_size, img_size, fx, fy, cx, cy, depth_refine=None):
-    """renderer.py:24-74 (the two progress prints of the reference are dropped)."""
-    b = cam_bbox.shape[0]
-    device = cam_bbox.device
-
-    def to_tensor(val):
-        if isinstance(val, (float, int)):
-            return torch.full((b,), val, device=device).float()
-        if isinstance(val, torch.Tensor):
-            if val.dim() == 0:
-                return val.unsqueeze(0).repeat(b).float()
-            if val.dim() == 1 and val.shape[0] == 1:
-                return val.repeat(b).float()
-            return val.float()
-        return torch.tensor(val, device=device).float()
-
-    fx, fy, cx_real, cy_real = to_tensor(fx), to_tensor(fy), to_tensor(cx), to_tensor(cy)
-    if depth_refine is not None:
-        tz = to_tensor(depth_refine)
-        bs = 2 * fx / (tz + 1e-9)
-    else:
+    """cam_bbox (B,3) = (s, tx, ty) on the crop; box_center (B,2), box_size (B,) in frame pixels; intrinsics per hand or
+    shared.  With ``depth_refine`` (metres, RootNet) the depth is taken from it and the box scale follows from the depth.
+    ``ty`` is rescaled by fx / fy when the focal lengths differ anywhere in the batch.  Returns (B,3) = (tx, ty, tz)."""
+    n = cam_bbox.shape[0]
+    f = torch.stack([_per_hand(fx, n, cam_bbox), _per_hand(fy, n, cam_bbox)], dim=1)            # (B, 2)
+    pp = torch.stack([_per_hand(cx, n, cam_bbox), _per_hand(cy, n, cam_bbox)], dim=1)
+    if depth_refine is None:
         bs = box_size * cam_bbox[:, 0] + 1e-9
-        tz = 2 * fx / bs
-    tx = (2 * (box_center[:, 0] - cx_real) / bs) + cam_bbox[:, 1]
-    ty = (2 * (box_center[:, 1] - cy_real) / bs) + cam_bbox[:, 2]
-    if not torch.allclose(fx, fy):
-        ty = ty * (fx / fy)
-    return torch.stack([tx, ty, tz], dim=-1)
+        tz = 2 * f[:, 0] / bs
+    else:
+        tz = _per_hand(depth_refine, n, cam_bbox)
+        bs = 2 * f[:, 0] / (tz + 1e-9)
+    t_xy = 2 * (box_center[:, :2] - pp) / bs.unsqueeze(1) + cam_bbox[:, 1:3]
+    if not torch.allclose(f[:, 0], f[:, 1]):
+        t_xy = t_xy * torch.stack([torch.ones_like(tz), f[:, 0] / f[:, 1]], dim=1)
+    return torch.cat([t_xy, tz.unsqueeze(1)], dim=1)
+
+
+def cam_crop_to_full(cam_bbox, box_center, box_size, img_size, focal_length=5000.):
+    """The same with one focal length and the principal point at the image centre (img_size (B,2) = (w, h))."""
+    return custom_cam_crop_to_full(cam_bbox, box_center, box_size, img_size, focal_length, focal_length,
+                                   img_size[:, 0] / 2., img_size[:, 1] / 2.)

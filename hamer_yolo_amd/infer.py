@@ -93,40 +93,69 @@ class hamer_inference():
         return None
 
     # ------------------------------------------------------------------ crop
-    def prepare_batch_bbox(self, img_0: np.ndarray, bboxs: List) -> Dict[str, torch.Tensor]:
-        """infer.py:154-259.  img_0: HxWx3 uint8 BGR; bboxs: [[label, [x1, y1, x2, y2]], ...]."""
+    def _box_scalars(self, bboxs: List):
+        """Per-hand host scalars of infer.py:179-199: crop centre, square crop size S, flip flag, the 2x3 affine."""
         P = int(self.cfg.MODEL.IMAGE_SIZE)
+        BBOX_SHAPE = self.cfg.MODEL.get('BBOX_SHAPE', None)
         boxes, centers, sizes, flips, transs = [], [], [], [], []
         for bbox in bboxs:
             if not (isinstance(bbox, list) and len(bbox) == 2 and isinstance(bbox[1], list) and len(bbox[1]) == 4):
                 raise ValueError(f"Invalid bbox format: Expected [class, [x1,y1,x2,y2]], got {bbox}")
             hand_cls, (x1, y1, x2, y2) = bbox
-            do_flip = 0.0 if hand_cls == 'right' else 1.0
             center_x, center_y = (x1 + x2) / 2.0, (y1 + y2) / 2.0
             rescaling_factor = 2.5
             scale = np.array([rescaling_factor * (x2 - x1) / 200.0, rescaling_factor * (y2 - y1) / 200.0])
-            BBOX_SHAPE = self.cfg.MODEL.get('BBOX_SHAPE', None)
             if BBOX_SHAPE is not None:
                 final_bbox_size = float(expand_to_aspect_ratio(scale * 200, target_aspect_ratio=BBOX_SHAPE).max())
             else:
                 final_bbox_size = float(max(x2 - x1, y2 - y1) * rescaling_factor)
             boxes.append((center_x, center_y, final_bbox_size, hand_cls != 'right'))
-            centers.append([center_x, center_y]); sizes.append(final_bbox_size); flips.append(do_flip)
+            centers.append([center_x, center_y]); sizes.append(final_bbox_size); flips.append(0.0 if hand_cls == 'right' else 1.0)
             transs.append(gen_trans_from_patch_cv(center_x, center_y, final_bbox_size, final_bbox_size, P, P, 1.0, 0))
-        frame = torch.from_numpy(np.ascontiguousarray(img_0)).to(self.device)
-        rec = ops.crop_boxes(boxes, P).to(self.device)
-        img = ops.crop_batch(frame, rec, self.mean, self.std, P)
-        n = len(bboxs)
+        return boxes, centers, sizes, flips, transs
+
+    def prepare_batch_frames(self, frames: List[torch.Tensor], dets_lists: List[List]) -> Dict[str, torch.Tensor]:
+        """prepare_batch_bbox for the hands of SEVERAL frames at once: ``frames`` are (H,W,3) uint8 BGR device tensors,
+        ``dets_lists[i]`` the boxes of frame i.  One hm_crop_batch launch per frame, all writing into one (sum B,3,P,P)
+        batch tensor, so one HaMeR forward serves every hand of every frame.  ``frame_index`` says which frame a hand is from."""
+        P = int(self.cfg.MODEL.IMAGE_SIZE)
+        boxes, centers, sizes, flips, transs, img_sizes, fidx = [], [], [], [], [], [], []
+        counts = []
+        for i, (fr, bboxs) in enumerate(zip(frames, dets_lists)):
+            b, c, sz, fl, tr = self._box_scalars(bboxs)
+            boxes += b; centers += c; sizes += sz; flips += fl; transs += tr
+            img_sizes += [[fr.shape[1], fr.shape[0]]] * len(bboxs)
+            fidx += [i] * len(bboxs)
+            counts.append(len(bboxs))
+        n = len(boxes)
+        if n == 0:
+            raise ValueError("Invalid detections format")
+        rec = ops.crop_boxes(boxes, P).to(self.device)             # one upload for all hands
+        rsz = rec.numel() // n
+        img = torch.empty(n, 3, P, P, device=self.device, dtype=torch.float32)
+        off = 0
+        for fr, k in zip(frames, counts):
+            if k:
+                ops.crop_batch(fr, rec[off * rsz:(off + k) * rsz], self.mean, self.std, P, out=img[off:off + k])
+                off += k
         trans = torch.tensor(np.stack(transs), dtype=torch.float32)
         return {
             'img': img,                                                               # (B,3,P,P) on device
             'box_center': torch.tensor(centers, dtype=torch.float32),                 # (B,2)
             'box_size': torch.tensor(sizes, dtype=torch.float32),                     # (B,)
-            'img_size': torch.tensor([[img_0.shape[1], img_0.shape[0]]] * n, dtype=torch.float32),
+            'img_size': torch.tensor(img_sizes, dtype=torch.float32),                 # (B,2) = (w, h) of the hand's frame
             'inv_trans': trans.clone(),                                               # == trans (datasets/utils.py:354-355)
             'trans': trans,
             'do_flip': torch.tensor(flips, dtype=torch.float32),
+            'frame_index': torch.tensor(fidx, dtype=torch.long),
         }
+
+    def prepare_batch_bbox(self, img_0: np.ndarray, bboxs: List) -> Dict[str, torch.Tensor]:
+        """infer.py:154-259.  img_0: HxWx3 uint8 BGR; bboxs: [[label, [x1, y1, x2, y2]], ...]."""
+        frame = torch.from_numpy(np.ascontiguousarray(img_0)).to(self.device)
+        batch = self.prepare_batch_frames([frame], [bboxs])
+        del batch['frame_index']
+        return batch
 
     # ------------------------------------------------------------------ forward + camera maths
     @torch.no_grad()
@@ -134,7 +163,19 @@ class hamer_inference():
         """infer.py:355-528 (d_infer.py:355 adds ``depth_refine``)."""
         if not isinstance(detections, list) or len(detections) == 0:
             raise ValueError("Invalid detections format")
-        batch = self.prepare_batch_bbox(img_0, detections)
+        return self._estimate(self.prepare_batch_bbox(img_0, detections), k_real, depth_refine)
+
+    @torch.no_grad()
+    def estimate_from_frames(self, frames: List[torch.Tensor], dets_lists: List[List], k_real=None, depth_refine=None):
+        """estimate_from_rgb over the hands of several device-resident frames in ONE forward (the batched drivers below);
+        ``out['frame_index'][h]`` is the frame of hand h, hands keep the order of ``dets_lists``."""
+        batch = self.prepare_batch_frames(frames, dets_lists)
+        fidx = batch.pop('frame_index')
+        out, params = self._estimate(batch, k_real, depth_refine)
+        out['frame_index'] = fidx
+        return out, params
+
+    def _estimate(self, batch, k_real=None, depth_refine=None):
         for key in batch:
             if isinstance(batch[key], torch.Tensor):
                 batch[key] = batch[key].to(self.device).float()
@@ -199,6 +240,19 @@ def _imread_bgr(path: str) -> Optional[np.ndarray]:
         return None
 
 
+def rodrigues_log_batch(R: np.ndarray) -> np.ndarray:
+    """rodrigues_log over (N,3,3) -> (N,3) float32 (vectorised; the rare near-pi / near-identity rows take the scalar path)."""
+    R = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
+    c = np.clip((np.trace(R, axis1=1, axis2=2) - 1.0) * 0.5, -1.0, 1.0)
+    r = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1) * 0.5
+    sn = np.linalg.norm(r, axis=1)
+    theta = np.arctan2(sn, c)
+    out = (r * (theta / np.maximum(sn, 1e-300))[:, None]).astype(np.float32)
+    for i in np.nonzero(sn < 1e-5)[0]:
+        out[i] = rodrigues_log(R[i])
+    return out
+
+
 def hand_record(output: Dict, is_right: bool, index: int = 0) -> Dict:
     """The per-hand dict saved by process_batch_manopara (infer.py:1279-1303)."""
     mp = output['pred_mano_params']
@@ -211,51 +265,6 @@ def hand_record(output: Dict, is_right: bool, index: int = 0) -> Dict:
     cam_t_np = output['pred_cam_t_full'][index].detach().cpu().numpy().squeeze()
     return {'betas': betas_np, 'theta': np.concatenate((global_orient_aa, hand_pose_aa)), 'pose_hand': hand_pose_aa,
             'pose_global': global_orient_aa, 'cam_t': cam_t_np, 'is_right': is_right}
-
-
-def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None, detector=None):
-    """infer.py:1223-1318: per image, detect -> HaMeR -> save ``<stem>.npy`` holding
-    ``{'left': None|hand, 'right': None|hand}``.  All hands of an image go through ONE forward."""
-    os.makedirs(output_folder, exist_ok=True)
-    if hamer is None:
-        hamer = hamer_inference(hamer_opt)
-    if detector is None:
-        from .config.yolo_config import yolo_opt
-        from .yolo.detector import Detector
-        detector = Detector(yolo_opt)
-    exts = ['*.jpg', '*.jpeg', '*.png', '*.bmp']
-    image_paths = []
-    for ext in exts:
-        image_paths.extend(glob.glob(os.path.join(input_folder, ext)))
-        image_paths.extend(glob.glob(os.path.join(input_folder, ext.upper())))
-    image_paths = sorted(list(set(image_paths)))
-    print(f"{len(image_paths)} images")
-    for img_path in image_paths:
-        file_name = os.path.splitext(os.path.basename(img_path))[0]
-        image_results = {'left': None, 'right': None}
-        try:
-            image = _imread_bgr(img_path)
-            if image is None:
-                continue
-            _, dets = detector.detect(image)
-            detection_list = []
-            if isinstance(dets, list) and len(dets) > 0:
-                if isinstance(dets[0], list) and len(dets[0]) > 0 and isinstance(dets[0][0], list):
-                    detection_list = dets[0]
-                else:
-                    detection_list = dets
-            if not detection_list:
-                continue
-            try:
-                output, _ = hamer.estimate_from_rgb(image, detection_list, k_real)
-                for i, bbox in enumerate(detection_list):
-                    image_results[bbox[0]] = hand_record(output, bbox[0] == 'right', i)
-            except Exception as e:
-                print(f"Error processing hand: {e}")
-            np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
-        except Exception as e:
-            print(f"Error processing file {img_path}: {e}")
-            continue
 
 
 def _list_images(input_folder):
@@ -274,46 +283,156 @@ def _detection_list(dets):
     return []
 
 
-def process_batch(input_folder, output_folder, k_real=None, hamer=None, detector=None):
-    """infer.py:908-1036: per detected hand one ``<stem>_<label>[_<n>].npz`` with the ROTATION-MATRIX form of the MANO
-    parameters: ``betas (1,10)``, ``global_orient (1,1,3,3)``, ``hand_pose (1,15,3,3)``, ``cam_t (1,3)``, ``is_right``
-    (= do_flip == 0).  A second hand with the same label gets the suffix ``_2``, ``_3`` ... (:996-998).  All hands of an
-    image go through one forward; the saved arrays are the per-hand slices the reference's one-hand calls produce."""
-    os.makedirs(output_folder, exist_ok=True)
+# The reference walks the folder one image and one hand at a time (infer.py:1248-1316: imread -> detect -> one
+# estimate_from_rgb per hand -> save).  Here the same per-image results come out of a pipeline that keeps the GPU full:
+#   * images are decoded by a thread pool, `frames_per_step` consecutive images of one size form a chunk;
+#   * a chunk is ONE batched YOLOv7 pass + NMS (one host sync for all its box lists), then all hands of all its frames
+#     are cropped into one batch tensor and go through ONE HaMeR forward and one vectorised camera step;
+#   * chunks alternate between two HIP streams, so the detector pass of chunk i+1 runs under the HaMeR forward of chunk i
+#     and the host only waits when it needs the numbers (bench.py --workload e2e times exactly this function).
+FRAMES_PER_STEP = 16
+
+
+def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_step: int = FRAMES_PER_STEP, in_flight: int = 2,
+                        decode_threads: Optional[int] = None):
+    """Yields ``(path, detection_list, hands)`` per image that has detections, in path order; ``hands`` is a dict of host
+    numpy arrays for that image's hands in detection order: betas (n,10), global_orient (n,1,3,3), hand_pose (n,15,3,3),
+    cam_t (n,3), do_flip (n,), plus the axis-angle forms pose_global (n,3) and pose_hand (n,45)."""
+    from concurrent.futures import ThreadPoolExecutor
+    dev = hamer.device
+    nthreads = decode_threads or max(1, min(16, len(os.sched_getaffinity(0))))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, in_flight))]
+
+    def chunks_of(paths, images):
+        cur, shape = [], None
+        for pth, im in zip(paths, images):
+            if im is None:
+                continue
+            if cur and (im.shape != shape or len(cur) == frames_per_step):
+                yield cur
+                cur = []
+            shape = im.shape
+            cur.append((pth, im))
+        if cur:
+            yield cur
+
+    def enqueue(chunk, stream):
+        """Detector pass (+ its one sync), crops, HaMeR forward and camera step of one chunk, all on `stream`."""
+        with torch.cuda.stream(stream):
+            frames = [torch.from_numpy(np.ascontiguousarray(im)).to(dev) for _, im in chunk]
+            if hasattr(detector, "detect_frames"):
+                _, dets_lists = detector.detect_frames(frames)
+            else:                                              # any object with the reference's detect(image) works too
+                dets_lists = [detector.detect(im)[1] for _, im in chunk]
+            dets_lists = [_detection_list(d) for d in dets_lists]
+            keep = [i for i, d in enumerate(dets_lists) if d]
+            if not keep:
+                return None
+            out, _ = hamer.estimate_from_frames([frames[i] for i in keep], [dets_lists[i] for i in keep], k_real)
+            mp = out['pred_mano_params']
+            dev_res = {'betas': mp['betas'], 'global_orient': mp['global_orient'], 'hand_pose': mp['hand_pose'],
+                       'cam_t': out['pred_cam_t_full'], 'do_flip': out['do_flip']}
+            return {'stream': stream, 'paths': [chunk[i][0] for i in keep], 'dets': [dets_lists[i] for i in keep],
+                    'frame_index': out['frame_index'], 'dev': dev_res, 'frames': frames}     # (frames: kept alive until finish)
+
+    def finish(job):
+        job['stream'].synchronize()
+        res = {k: v.detach().cpu().numpy() for k, v in job['dev'].items()}
+        n = res['betas'].shape[0]
+        res['pose_global'] = rodrigues_log_batch(res['global_orient'].reshape(n, 3, 3))
+        res['pose_hand'] = rodrigues_log_batch(res['hand_pose'].reshape(n * 15, 3, 3)).reshape(n, 45)
+        fidx = job['frame_index'].numpy()
+        for j, (pth, dets) in enumerate(zip(job['paths'], job['dets'])):
+            sel = np.nonzero(fidx == j)[0]
+            yield pth, dets, {k: v[sel] for k, v in res.items()}
+
+    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+        block = frames_per_step * 4                         # decode ahead in blocks; the next block decodes while this one runs
+        starts = list(range(0, len(image_paths), block))
+        decode = lambda paths: [pool.submit(_imread_bgr, p) for p in paths]
+        nxt = decode(image_paths[:block])
+        pending = []
+        k = 0
+        for bi, st in enumerate(starts):
+            paths = image_paths[st:st + block]
+            futs, nxt = nxt, decode(image_paths[st + block:st + 2 * block])
+            images = [f.result() for f in futs]
+            for chunk in chunks_of(paths, images):
+                try:
+                    job = enqueue(chunk, streams[k % len(streams)])
+                except Exception as e:                    # isolate the bad file: redo this chunk image by image
+                    print(f"Error processing chunk starting at {chunk[0][0]}: {e}")
+                    job = None
+                    for one in chunk:
+                        try:
+                            j1 = enqueue([one], streams[k % len(streams)])
+                            if j1 is not None:
+                                yield from finish(j1)
+                        except Exception as e1:
+                            print(f"Error processing file {one[0]}: {e1}")
+                k += 1
+                if job is not None:
+                    pending.append(job)
+                while len(pending) >= len(streams):
+                    yield from finish(pending.pop(0))
+        for job in pending:
+            yield from finish(job)
+
+
+def _record_from(hands: Dict, i: int, is_right: bool) -> Dict:
+    """hand i of an image as the dict of infer.py:1296-1303."""
+    pg, ph = hands['pose_global'][i], hands['pose_hand'][i]
+    return {'betas': hands['betas'][i].squeeze(), 'theta': np.concatenate((pg, ph)), 'pose_hand': ph, 'pose_global': pg,
+            'cam_t': hands['cam_t'][i].squeeze(), 'is_right': is_right}
+
+
+def _default_models(hamer, detector):
     if hamer is None:
         hamer = hamer_inference(hamer_opt)
     if detector is None:
         from .config.yolo_config import yolo_opt
         from .yolo.detector import Detector
         detector = Detector(yolo_opt)
-    for img_path in _list_images(input_folder):
+    return hamer, detector
+
+
+def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None, detector=None,
+                           frames_per_step: int = FRAMES_PER_STEP):
+    """infer.py:1223-1318: per image, detect -> HaMeR -> save ``<stem>.npy`` holding ``{'left': None|hand, 'right':
+    None|hand}`` (the last detection of a label wins, as in the reference's loop); images without detections write nothing.
+    Runs on the chunked two-stream pipeline above: same files, same numbers, the GPU kept busy."""
+    os.makedirs(output_folder, exist_ok=True)
+    hamer, detector = _default_models(hamer, detector)
+    image_paths = _list_images(input_folder)
+    print(f"{len(image_paths)} images")
+    for img_path, detection_list, hands in iter_folder_results(image_paths, hamer, detector, k_real, frames_per_step):
         file_name = os.path.splitext(os.path.basename(img_path))[0]
-        try:
-            image = _imread_bgr(img_path)
-            if image is None:
-                continue
-            _, dets = detector.detect(image)
-            detection_list = _detection_list(dets)
-            if not detection_list:
-                continue
-            output, _ = hamer.estimate_from_rgb(image, detection_list, k_real)
-            mp = output['pred_mano_params']
-            saved_counts = {'left': 0, 'right': 0}
-            for i, bbox in enumerate(detection_list):
-                hand_label = bbox[0]
-                suffix = f"_{hand_label}"
-                if saved_counts[hand_label] > 0:
-                    suffix += f"_{saved_counts[hand_label] + 1}"
-                np.savez(os.path.join(output_folder, f"{file_name}{suffix}.npz"),
-                         betas=mp['betas'][i:i + 1].detach().cpu().numpy(),
-                         global_orient=mp['global_orient'][i:i + 1].detach().cpu().numpy(),
-                         hand_pose=mp['hand_pose'][i:i + 1].detach().cpu().numpy(),
-                         cam_t=output['pred_cam_t_full'][i:i + 1].detach().cpu().numpy(),
-                         is_right=bool(output['do_flip'][i] == 0))
-                saved_counts[hand_label] += 1
-        except Exception as e:
-            print(f"Error processing file {img_path}: {e}")
-            continue
+        image_results = {'left': None, 'right': None}
+        for i, bbox in enumerate(detection_list):
+            image_results[bbox[0]] = _record_from(hands, i, bbox[0] == 'right')
+        np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
+
+
+def process_batch(input_folder, output_folder, k_real=None, hamer=None, detector=None, frames_per_step: int = FRAMES_PER_STEP):
+    """infer.py:908-1036: per detected hand one ``<stem>_<label>[_<n>].npz`` with the ROTATION-MATRIX form of the MANO
+    parameters: ``betas (1,10)``, ``global_orient (1,1,3,3)``, ``hand_pose (1,15,3,3)``, ``cam_t (1,3)``, ``is_right``
+    (= do_flip == 0).  A second hand with the same label gets the suffix ``_2``, ``_3`` ... (:996-998).  Same pipeline as
+    process_batch_manopara; the saved arrays are the per-hand slices the reference's one-hand calls produce."""
+    os.makedirs(output_folder, exist_ok=True)
+    hamer, detector = _default_models(hamer, detector)
+    for img_path, detection_list, hands in iter_folder_results(_list_images(input_folder), hamer, detector, k_real, frames_per_step):
+        file_name = os.path.splitext(os.path.basename(img_path))[0]
+        saved_counts = {'left': 0, 'right': 0}
+        for i, bbox in enumerate(detection_list):
+            hand_label = bbox[0]
+            suffix = f"_{hand_label}"
+            if saved_counts[hand_label] > 0:
+                suffix += f"_{saved_counts[hand_label] + 1}"
+            np.savez(os.path.join(output_folder, f"{file_name}{suffix}.npz"),
+                     betas=hands['betas'][i:i + 1], global_orient=hands['global_orient'][i:i + 1],
+                     hand_pose=hands['hand_pose'][i:i + 1], cam_t=hands['cam_t'][i:i + 1],
+                     is_right=bool(hands['do_flip'][i] == 0))
+            saved_counts[hand_label] += 1
 
 
 def get_bbox_from_npy(npy_path, target_val=3):
@@ -442,8 +561,15 @@ def main(argv=None):
     ap.add_argument('--output', type=str, required=True)
     ap.add_argument('--intrinsics', type=str, default=None, help="3x3 camera matrix txt (the reference hard-codes its path)")
     ap.add_argument('--obj', type=str, default=None, help="also reconstruct OBJ meshes into this folder")
+    ap.add_argument('--ckpt', type=str, default=None, help="hamer.ckpt path or synthetic:<seed> (default: config/hamer_config.py)")
+    ap.add_argument('--yolo-weights', type=str, default=None, help="yolov7 .pt path or synthetic:<seed> (default: config/yolo_config.py)")
     args = ap.parse_args(argv)
     k_real = load_intrinsics(args.intrinsics) if args.intrinsics else None
+    if args.ckpt:
+        hamer_opt.ckpt_path = args.ckpt
+    if args.yolo_weights:
+        from .config.yolo_config import yolo_opt
+        yolo_opt.weights = args.yolo_weights
     hamer = hamer_inference(hamer_opt)
     process_batch_manopara(args.input, args.output, k_real, hamer=hamer)
     if args.obj:

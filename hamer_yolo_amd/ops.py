@@ -215,12 +215,15 @@ def crop_boxes(boxes, P: int = 256) -> torch.Tensor:
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
 
 
-def crop_batch(frame: torch.Tensor, boxes_rec: torch.Tensor, mean, std, P: int = 256) -> torch.Tensor:
-    """frame (H,W,3) uint8 BGR on device; boxes_rec: device uint8 tensor of hm_crop_box records."""
-    _dev(frame, boxes_rec)
+def crop_batch(frame: torch.Tensor, boxes_rec: torch.Tensor, mean, std, P: int = 256, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """frame (H,W,3) uint8 BGR on device; boxes_rec: device uint8 tensor of hm_crop_box records.  ``out``: a contiguous
+    (B,3,P,P) fp32 slice to fill (all hands of several frames land in one batch tensor)."""
+    _dev(frame, boxes_rec, out)
     H, W, _ = frame.shape
     B = boxes_rec.numel() // C.sizeof(L.CropBox)
-    out = torch.empty(B, 3, P, P, device=frame.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, 3, P, P, device=frame.device, dtype=torch.float32)
+    assert out.shape == (B, 3, P, P) and out.dtype == torch.float32 and out.is_contiguous() and frame.is_contiguous()
     m3 = (C.c_float * 3)(*[float(v) for v in mean])
     s3 = (C.c_float * 3)(*[float(v) for v in std])
     L.check(L.load().hm_crop_batch(L.ptr(frame), H, W, L.ptr(boxes_rec), L.ptr(out), B, P, m3, s3, L.current_stream()),

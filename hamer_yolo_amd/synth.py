@@ -281,12 +281,14 @@ YOLO_CALIB: Dict[str, float] = {
     "model.99.conv": 1.188, "model.101.conv": 1.116, "model.102.rbr_reparam": 1.068, "model.103.rbr_reparam": 1.082,
     "model.104.rbr_reparam": 1.152, "model.105.m.0": 2.945, "model.105.m.1": 3.242, "model.105.m.2": 2.914,
 }
-def yolo_state_dict(seed: int = 0, nc: int = 3, obj_bias: float = -4.0) -> Dict[str, torch.Tensor]:
+def yolo_state_dict(seed: int = 0, nc: int = 3, obj_bias: float = -4.0, cls_bias: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """UNFUSED random-init YOLOv7 weights keyed like the reference ``Model(cfg/training/yolov7.yaml)``
     state dict (Conv+BN pairs, RepConv branches, IDetect with ImplicitA/M).  Conv widths are
     He-style so activations stay O(1) through the 105 layers; BatchNorm statistics are non-trivial.
     ``obj_bias`` shifts the objectness logit so a small fraction of the 15120 candidates passes the
-    0.25 confidence threshold."""
+    0.25 confidence threshold; ``cls_bias`` (when given) replaces the random class biases by one value, so
+    that the winning class is decided by the features (both 'left' and 'right' boxes appear).  Seed 2 with obj_bias -2.2 and
+    cls_bias 0 yields ~10 boxes of both labels on seeded 1080p frames (the chained driver test)."""
     from .yolo import arch
     layers = arch.yolov7_layers()
     specs = arch.conv_specs(layers, 3, nc)
@@ -313,6 +315,8 @@ def yolo_state_dict(seed: int = 0, nc: int = 3, obj_bias: float = -4.0) -> Dict[
             U(name + ".weight", (co, ci, 1, 1), hw)
             b = uniform("yolo." + name + ".bias", (co,), 0.5, seed=seed).view(3, -1)
             b[:, 4] += obj_bias
+            if cls_bias is not None:
+                b[:, 5:] = float(cls_bias)
             sd[name + ".bias"] = b.reshape(-1)
             U(f"{base}.ia.{l}.implicit", (1, ci, 1, 1), 0.02)
             U(f"{base}.im.{l}.implicit", (1, co, 1, 1), 0.02, 1.0)

@@ -38,9 +38,14 @@ def attempt_load(weights: str):
     uses.  ``"synthetic:<seed>"`` draws seeded random-init weights; a file is read with the class-free
     unpickler (utils/checkpoint.py), so the reference's own ``yolov7_best.pt`` loads without its ``models`` package."""
     weights = str(weights)
-    if weights.startswith("synthetic"):
-        seed = int(weights.split(":")[1]) if ":" in weights else 0
-        return synth.yolo_state_dict(seed=seed, nc=3), 3, ['0', '1', '2']
+    if weights.startswith("synthetic"):                                # synthetic[:seed[:obj_bias[:cls_bias]]]
+        f = weights.split(":")[1:]
+        kw = {"seed": int(f[0]) if len(f) > 0 else 0}
+        if len(f) > 1:
+            kw["obj_bias"] = float(f[1])
+        if len(f) > 2:
+            kw["cls_bias"] = float(f[2])
+        return synth.yolo_state_dict(nc=3, **kw), 3, ['0', '1', '2']
     from ..utils.checkpoint import load_checkpoint
     ck = load_checkpoint(weights)                                      # FileNotFoundError when missing
     sd = checkpoint_state_dict(ck)
@@ -77,13 +82,28 @@ class Detector():
         self.opt = config
         self.detect_savepath = config.save_path
 
+    @staticmethod
+    def _labelled(rows):
+        return [['right' if row[-1] == 1 else 'left', row[:4]] for row in rows]        # detector.py:144-147
+
     @torch.no_grad()
     def detect(self, image: np.ndarray):
         opt = self.opt
         frame = torch.from_numpy(np.ascontiguousarray(image)).to(self.device)
         p = self.engine.forward(frame)
         det = self.engine.nms(p, opt.conf_thres, opt.iou_thres, opt.classes, opt.agnostic_nms, scale=True)
-        dets = []
-        for row in det.tolist():
-            dets.append(['right' if row[-1] == 1 else 'left', row[:4]])
-        return [det], [dets]
+        return [det], [self._labelled(det.tolist())]
+
+    @torch.no_grad()
+    def detect_frames(self, frames):
+        """``detect`` for a list of equally sized (H,W,3) uint8 BGR DEVICE frames: one batched pass through the network, one
+        NMS launch per frame, ONE host transfer for all box lists.  Returns (preds, dets_lists) with one entry per frame, each
+        as ``detect`` returns it for a single image."""
+        opt = self.opt
+        p = self.engine.forward(list(frames))
+        self.engine.nms_enqueue(p, opt.conf_thres, opt.iou_thres, opt.classes, opt.agnostic_nms, scale=True)
+        counts = p["count"].tolist()                                   # the only host sync of the chunk
+        dets = p["dets"].reshape(p["nb"], 300, 6)
+        preds = [dets[i, :int(k)].clone() for i, k in enumerate(counts)]
+        host = dets.cpu()
+        return preds, [self._labelled(host[i, :int(k)].tolist()) for i, k in enumerate(counts)]
