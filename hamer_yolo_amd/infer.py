@@ -102,6 +102,10 @@ class hamer_inference():
             if not (isinstance(bbox, list) and len(bbox) == 2 and isinstance(bbox[1], list) and len(bbox[1]) == 4):
                 raise ValueError(f"Invalid bbox format: Expected [class, [x1,y1,x2,y2]], got {bbox}")
             hand_cls, (x1, y1, x2, y2) = bbox
+            if not (x2 > x1 or y2 > y1):
+                # a box clipped to nothing (scale_coords + round at the frame border) has crop size 0: the reference hands
+                # cv2.getAffineTransform three coincident points and gets a meaningless patch; here it is an error
+                raise ValueError(f"Invalid bbox format: empty box {bbox}")
             center_x, center_y = (x1 + x2) / 2.0, (y1 + y2) / 2.0
             rescaling_factor = 2.5
             scale = np.array([rescaling_factor * (x2 - x1) / 200.0, rescaling_factor * (y2 - y1) / 200.0])
@@ -267,6 +271,13 @@ def hand_record(output: Dict, is_right: bool, index: int = 0) -> Dict:
             'pose_global': global_orient_aa, 'cam_t': cam_t_np, 'is_right': is_right}
 
 
+def box_has_area(det) -> bool:
+    """False for a detection whose box was clipped to nothing at the frame border (x2 <= x1 and y2 <= y1): it has no crop
+    (size 0) and the folder drivers skip it -- the reference's per-hand try/except plays that role (infer.py:1306-1308)."""
+    x1, y1, x2, y2 = det[1]
+    return x2 > x1 or y2 > y1
+
+
 def _list_images(input_folder):
     image_paths = []
     for ext in ['*.jpg', '*.jpeg', '*.png', '*.bmp']:
@@ -324,7 +335,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
                 _, dets_lists = detector.detect_frames(frames)
             else:                                              # any object with the reference's detect(image) works too
                 dets_lists = [detector.detect(im)[1] for _, im in chunk]
-            dets_lists = [_detection_list(d) for d in dets_lists]
+            dets_lists = [[d for d in _detection_list(dl) if box_has_area(d)] for dl in dets_lists]
             keep = [i for i, d in enumerate(dets_lists) if d]
             if not keep:
                 return None

@@ -17,7 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from hamer_yolo_amd import synth
-from hamer_yolo_amd.infer import hamer_inference, main, process_batch_manopara
+from hamer_yolo_amd.infer import box_has_area, hamer_inference, main, process_batch_manopara
 from hamer_yolo_amd.yolo import arch, fuse
 from hamer_yolo_amd.yolo.detector import Detector
 from oracle import crop_ref, yolo_ref
@@ -88,11 +88,11 @@ def test_folder_of_1080p_frames_through_detector_and_hamer_to_npy(tmp_path):
         # link 1: the network in the oracle's half arithmetic, and the box list = oracle NMS + scale_coords on the GPU's prediction
         with torch.no_grad():
             _, _, ref_pred = yolo_ref.detect(layers, fused, fr, 3, arch.ANCHORS, emu="fp16")
-        assert float((gpu_pred[..., 4:] - ref_pred[..., 4:]).abs().max()) < 1e-2
+        assert float((gpu_pred[..., 4:] - ref_pred[..., 4:]).abs().max()) < 2e-2           # the half reordering floor (test_gpu_yolo)
         mine = yolo_ref.non_max_suppression(gpu_pred, 0.25, 0.35, [0, 1, 2], True)[0]
         mine[:, :4] = yolo_ref.scale_coords((p["lp"].out_h, p["lp"].out_w), mine[:, :4], fr.shape).round()
         assert torch.equal(pred[0].cpu(), mine)
-        dets = dets_list[0]
+        dets = [d for d in dets_list[0] if box_has_area(d)]             # boxes clipped to nothing at the border have no crop
         if not dets:
             assert name == "c_empty"
             continue
