@@ -187,7 +187,7 @@ def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
         assert float(d32.max()) < 0.3 and float(d32.mean()) < 0.02
     assert float((pred[:, 4:] - epred[0, :, 4:]).abs().max()) < 2e-2
     size = epred[0, :, 2:4].abs().mean(1, keepdim=True).clamp_min(8.0)
-    assert float(((pred[:, :4] - epred[0, :, :4]).abs() / size).max()) < 5e-2
+    assert float(((pred[:, :4] - epred[0, :, :4]).abs() / size).max()) < 1e-1       # wh = (2 sigma)^2 anchor doubles the relative logit error
     # loose: the reference's own fp32 output rows
     ref_rows = torch.from_numpy(g["pred_rows"])
     got = pred[::9]
