@@ -195,6 +195,8 @@ def main():
                     help="batches in flight: consecutive forwards alternate between this many HIP streams (own workspace and outputs "
                          "each), so one batch's HBM-bound phases overlap another's MFMA phases; 1 = strictly one after the other; "
                          "default 2")
+    ap.add_argument("--fold-ln", action="store_true", help="deferred LayerNorm (LN1/LN2 folded into the neighbouring GEMM epilogues)")
+    ap.add_argument("--gemm-variant", type=int, default=-1, help="force one GEMM tile variant (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -220,7 +222,9 @@ def main():
     sd0 = synth.hamer_state_dict(cfg, seed=0, device=dev) if rank == 0 else None
     sd = shard.broadcast_state_dict(sd0, dev, src=0, half_dtype=dtype) if world > 1 else sd0
     mano_cpu = synth.mano_params(seed=0)
-    eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype, fp8=(args.dtype == "fp8"))
+    eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype, fp8=(args.dtype == "fp8"), fold_ln=args.fold_ln or None)
+    if args.gemm_variant >= 0:
+        L.check(L.load().hm_gemm_set_variant(args.gemm_variant), "hm_gemm_set_variant")
     nfl = args.in_flight if args.in_flight > 0 else 2
     ctxs = eng.contexts(B, nfl)
     out = eng.alloc_outputs(B)

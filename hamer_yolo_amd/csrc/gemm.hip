@@ -51,6 +51,26 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return 0.5f * v * (v >= 0.f ? 2.0f - q : q);
 }
 
+// The same GELU on two values at once: the polynomial, the products and the final combination become v_pk_fma_f32 /
+// v_pk_mul_f32 (two results per issue slot; nothing competes for the VALU in the epilogue), ~10 issue slots per element
+// instead of ~17.  gelu(v) = max(v, 0) - 0.5 |v| (1 - erf(|v| / sqrt 2)), exp(-z^2) as exp2(v^2 * (-0.5 log2 e)).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t v) {
+  const f32x2_t av = __builtin_elementwise_abs(v);
+  const f32x2_t d = __builtin_elementwise_fma(av, f32x2_t{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, f32x2_t{1.0f, 1.0f});
+  f32x2_t t;
+  t[0] = __builtin_amdgcn_rcpf(d[0]); t[1] = __builtin_amdgcn_rcpf(d[1]);
+  f32x2_t p = __builtin_elementwise_fma(t, f32x2_t{1.061405429f, 1.061405429f}, f32x2_t{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(t, p, f32x2_t{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(t, p, f32x2_t{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(t, p, f32x2_t{0.254829592f, 0.254829592f});
+  const f32x2_t x2 = v * v * f32x2_t{-0.5f * 1.44269504088896340736f, -0.5f * 1.44269504088896340736f};
+  f32x2_t e;
+  e[0] = __builtin_amdgcn_exp2f(x2[0]); e[1] = __builtin_amdgcn_exp2f(x2[1]);
+  const f32x2_t q = p * t * e;                          // 1 - erf(|v| / sqrt 2)
+  return __builtin_elementwise_fma(av * q, f32x2_t{-0.5f, -0.5f}, __builtin_elementwise_max(v, f32x2_t{0.f, 0.f}));
+}
+
 // Tile walk.  Blocks b, b+8, .. share an XCD (and its 4 MB L2); xcd_remap gives every XCD a contiguous run of
 // tile ids, and inside that run tiles are ordered in super-rows of `group_m` M-tiles, M fastest, so the ~32
 // tiles an XCD works on at once form a group_m x (32 / group_m) rectangle: group_m A panels and 32/group_m W
@@ -78,7 +98,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "add this vmcnt immediate");
 }
 
-constexpr int epi_cgn(int MI, int NI) { return NI < 16 / MI ? NI : 16 / MI; }
+// n-subtiles per epilogue column group: the largest divisor of NI that keeps a wave's staging within 16 KB (<= 16 / MI)
+constexpr int epi_cgn(int MI, int NI) {
+  int c = NI < 16 / MI ? NI : 16 / MI;
+  while (NI % c != 0) --c;
+  return c;
+}
 constexpr int epi_stage_bytes(int MI, int NI) { return MI * 16 * epi_cgn(MI, NI) * 64; }
 
 // Epilogue of one wave through LDS.  acc[ni][mi] holds C[mb + mi*16 + (lane&15)][nb + ni*16 + 4*(lane>>4) .. +3]
@@ -107,7 +132,7 @@ __device__ __forceinline__ float row8_sum(float v) {
   return v;
 }
 
-template <class T, int EPI, int MI, int NI>
+template <class T, int EPI, int MI, int NI, bool RESID_REGS = true>
 __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI], int mb, int nb, int lane, char* wlds,
                                          const float2* rowstat, const float* cbias, const float* cvec2, int split) {
   using elem = typename T::elem;
@@ -115,14 +140,17 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
   // transposed accumulators and the residual rows, which arrive by LDS-DMA (no registers, all in flight at once)
   constexpr int CGN0 = epi_cgn(MI, NI);
   constexpr bool LNOUT = EPI == HM_EPI_RESID_LN, LNIN = epi_ln_in(EPI);
-  constexpr bool RES = EPI == HM_EPI_RESID_F32 || LNOUT;
+  constexpr bool RESREG = EPI == HM_EPI_RESID_F32 && RESID_REGS;   // residual rows prefetched into registers, one column group ahead
+  constexpr bool RES = LNOUT || (EPI == HM_EPI_RESID_F32 && !RESID_REGS);   // residual rows through LDS (deferred-LN producer; fp8 kernel: no registers to spare)
   constexpr bool MX8 = EPI == HM_EPI_GELU_MX8;
   constexpr bool ACT_GELU = EPI == HM_EPI_GELU || EPI == HM_EPI_LN_GELU || MX8;
-  constexpr int CGN = (RES && CGN0 > 1) ? CGN0 / 2 : CGN0;
+  // (RESREG keeps the half-width column group too: two groups of residual rows in registers are 2 x ITS x 4 VGPRs)
+  constexpr int CGN = ((RES || RESREG) && CGN0 > 1) ? CGN0 / 2 : CGN0;
   constexpr int NCH = CGN * 4;                     // 16-byte chunks per staged row (4, 8 or 16)
   constexpr int RS = NCH * 16;                     // staged row stride in bytes
   constexpr int RPI = 64 / NCH;                    // rows per row-major instruction (1 KiB)
   constexpr int ITS = MI * 16 / RPI;               // row-major instructions per column group
+  constexpr int NCG = NI / CGN;                    // column groups of the wave's strip
   const int arow = lane & 15, apiece = lane >> 4;  // accumulator layout
   const int rrow = lane / NCH, rslot = lane % NCH; // row-major layout
   // cbias / cvec2: this wave's columns of the bias (zeros when there is none) and of ln_gamma / ln_colsum, staged in
@@ -133,9 +161,32 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
   static_assert(!LNOUT || ((CGN * 16 <= 64) && (64 % (CGN * 16) == 0) && (NI * 16) % 64 == 0), "LN statistics groups are 64 columns");
   static_assert(!LNIN || NCH >= 8, "deferred-LN consumers use the 16-byte store path");
   float s1[LNOUT ? ITS : 1], s2[LNOUT ? ITS : 1];
+  // RESREG.  The fp32 residual epilogue moves 2 x 4 bytes per output element through HBM and sits at the HBM bound; what
+  // can be saved is latency: the rows of column group cg + 1 are requested (row-major, 16 bytes per lane, straight into
+  // registers -- the K loop's fragment registers are free by now) before group cg is processed, so each wave pays ONE
+  // exposed round trip instead of one per column group.
+  f32x4_t rr[RESREG ? 2 : 1][RESREG ? ITS : 1];
+  auto resid_fetch = [&](int cg, f32x4_t (&dst)[RESREG ? ITS : 1]) {
+    if constexpr (RESREG) {
+      const int ncol0 = nb + cg * CGN * 16;
 #pragma unroll
-  for (int cg = 0; cg < NI / CGN; ++cg) {
+      for (int it = 0; it < ITS; ++it) {
+        const int row = it * RPI + rrow;
+        int m = mb + row, n = ncol0 + ((rslot ^ (row & (NCH - 1))) << 2);
+        m = m < g.M ? m : g.M - 1;                 // out-of-range lanes fetch a valid address; their result is never stored
+        n = n < g.N ? n : 0;
+        const int rm = g.resid_mod > 0 ? m % g.resid_mod : m;
+        dst[it] = *(const f32x4_t*)(g.resid + (size_t)rm * g.ldr + n);
+      }
+    }
+  };
+  if constexpr (RESREG) resid_fetch(0, rr[0]);
+#pragma unroll
+  for (int cg = 0; cg < NCG; ++cg) {
     const int ncol0 = nb + cg * CGN * 16;
+    if constexpr (RESREG) {
+      if (cg + 1 < NCG) resid_fetch(cg + 1, rr[(cg + 1) & 1]);
+    }
     if (RES) {                                     // residual rows -> LDS, row-major, same (row, slot) image as the reads below
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
@@ -186,7 +237,11 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
           // so a row's lanes are all in or all out: the quad reduction sees no inactive lane)
           float amax = 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { v0[q] = gelu_fast(v0[q]); v1[q] = gelu_fast(v1[q]); amax = fmaxf(amax, fmaxf(fabsf(v0[q]), fabsf(v1[q]))); }
+          for (int q = 0; q < 4; ++q) {
+            const f32x2_t gq = gelu_fast2(f32x2_t{v0[q], v1[q]});
+            v0[q] = gq[0]; v1[q] = gq[1];
+            amax = fmaxf(amax, fmaxf(fabsf(v0[q]), fabsf(v1[q])));
+          }
           const unsigned sb = mx8_scale_byte(quad_max(amax));
           const float inv = mx8_inv_scale(sb);
           int2 o8;
@@ -200,7 +255,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float a = v0[q], b = v1[q];
-          if (ACT_GELU) { a = gelu_fast(a); b = gelu_fast(b); }
+          if (ACT_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0]; b = gq[1]; }
           else if (EPI == HM_EPI_SILU) { a = silu(a); b = silu(b); }
           o[q] = (elem)a; o[4 + q] = (elem)b;
         }
@@ -264,13 +319,14 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         }
       }
     } else {
-#pragma unroll 2
+#pragma unroll
       for (int it = 0; it < ITS; ++it) {
         const int row = it * RPI + rrow, m = mb + row;
         const int n = ncol0 + ((rslot ^ (row & (NCH - 1))) << 2);
         f32x4_t v = *(const f32x4_t*)(wlds + row * RS + rslot * 16);
         f32x4_t r = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (RES) r = *(const f32x4_t*)(rlds + row * RS + rslot * 16);
+        if constexpr (RESREG) r = rr[cg & 1][it];
         if (m >= g.M || n >= g.N) continue;
         {
           const f32x4_t bi = *(const f32x4_t*)(cbias + (n - nb));
@@ -292,7 +348,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         }
-        if (RES) {
+        if (RES || RESREG) {
           *(f32x4_t*)((float*)g.C + (size_t)m * g.ldc + n) = v + r;
         } else if (EPI == HM_EPI_F32) {
           *(f32x4_t*)((float*)g.C + ((size_t)split * g.M + m) * g.ldc + n) = v;      // split-K: slab `split` of C
@@ -603,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const KArgs g) {
     for (int mi = 0; mi < MI; ++mi) acc[ni][mi] *= ws;
   }
   __builtin_amdgcn_s_barrier();                                   // (the ring is reused as epilogue staging)
-  epilogue<TBf16, EPI, MI, NI>(g, acc, m0 + wr * 64, n0 + wc * 128, lane, smem + wave * epi_stage_bytes(MI, NI),
+  epilogue<TBf16, EPI, MI, NI, false>(g, acc, m0 + wr * 64, n0 + wc * 128, lane, smem + wave * epi_stage_bytes(MI, NI),
                                rowstat + wr * 64, colvec + wc * 128, colvec + BN + wc * 128, 0);
 }
 
@@ -811,6 +867,7 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
     case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
+    case 25: return launch_cfg<T, EPI, 4, 2, 4, 10, 2, false, 64, 2>(g, s, "hm_gemm"); // 256x320, waves 4x2 (64x160 each), 2 stages (144 KB)
     case 24:                                                                           // X two K-steps ahead in a 3-slot ring (gemm_x3_kernel)
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
         if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_rs<T, EPI>(g, s);   // 32-bit lane offsets
@@ -840,7 +897,7 @@ bool variant_ok(int v) {
 #ifdef HM_ABLATIONS
   if (v == 14 || v == 15 || v == 18 || v == 20) return true;
 #endif
-  return (v >= 0 && v <= 11) || (v >= 21 && v <= 24);
+  return (v >= 0 && v <= 11) || (v >= 21 && v <= 25);
 }
 
 int pick_variant(const KArgs& g) {
@@ -915,7 +972,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..24");
+  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..25");
   g_variant = v;
   return HM_OK;
 }

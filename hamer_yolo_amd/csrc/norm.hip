@@ -135,15 +135,109 @@ __global__ __launch_bounds__(256, 8) void layernorm_mx8_kernel(const float* __re
   }
 }
 
+// The production LayerNorm (no split-K accumulation): the same arithmetic, two changes for bandwidth.
+//  * Rows per wave.  12288 rows on one-row waves are 1.5 x the 8192 waves the chip holds: the second half-round leaves
+//    half of the machine idle.  Here the grid is sized to be resident at once and every wave walks `rows_per_wave` rows
+//    (stride = waves in the grid, so neighbouring waves stream neighbouring rows), the next row's loads issued before the
+//    current row's reductions.
+//  * 16-byte stores of the 16-bit output.  A lane holds columns 4l..4l+3 of every 256-column piece (16-byte loads); for the
+//    output it trades halves with its neighbour (DPP swap inside lane pairs) so that the even lane stores columns
+//    4l..4l+7 of piece j and the odd lane those of piece j+1: every store instruction is 16 bytes per lane.
+__device__ __forceinline__ unsigned pair_swap(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+}
+template <class OutT> __device__ __forceinline__ uint2 pack4h(f32x4_t v);
+template <> __device__ __forceinline__ uint2 pack4h<__bf16>(f32x4_t v) {
+  bf16x4_t o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+  return __builtin_bit_cast(uint2, o);
+}
+template <> __device__ __forceinline__ uint2 pack4h<_Float16>(f32x4_t v) {
+  f16x4_t o; o[0] = (_Float16)v[0]; o[1] = (_Float16)v[1]; o[2] = (_Float16)v[2]; o[3] = (_Float16)v[3];
+  return __builtin_bit_cast(uint2, o);
+}
+
+template <class OutT, int MAXJ>
+__global__ __launch_bounds__(256, 4) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, OutT* __restrict__ out, int M,
+                                                                int D, float eps, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const bool full = D == MAXJ * 256;                 // every piece complete: the paired 16-byte stores apply
+  f32x4_t v[MAXJ], nx[MAXJ];
+  auto fetch = [&](int row, f32x4_t (&dst)[MAXJ]) {
+    const float* xr = x + (size_t)row * D;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = lane * 4 + j * 256;
+      dst[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (i < D) dst[j] = *(const f32x4_t*)(xr + i);
+    }
+  };
+  int row = wave;
+  if (row < M) fetch(row, v);
+  for (int k = 0; k < rows_per_wave && row < M; ++k, row += nwaves) {
+    const int nrow = row + nwaves;
+    if (k + 1 < rows_per_wave && nrow < M) fetch(nrow, nx);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = lane * 4 + j * 256;
+      if (i < D) {
+        const f32x4_t d = v[j] - mean;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    OutT* orow = out + (size_t)row * D;
+    if constexpr (sizeof(OutT) == 2) {
+      if (full) {
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int j = 0; j + 1 < MAXJ; j += 2) {
+          const int i0 = lane * 4 + j * 256, i1 = i0 + 256;
+          const uint2 p0 = pack4h<OutT>((v[j] - mean) * rstd * *(const f32x4_t*)(gamma + i0) + *(const f32x4_t*)(beta + i0));
+          const uint2 p1 = pack4h<OutT>((v[j + 1] - mean) * rstd * *(const f32x4_t*)(gamma + i1) + *(const f32x4_t*)(beta + i1));
+          const uint2 send = odd ? p0 : p1;
+          const uint2 recv = uint2{pair_swap(send.x), pair_swap(send.y)};
+          const uint4 o = odd ? uint4{recv.x, recv.y, p1.x, p1.y} : uint4{p0.x, p0.y, recv.x, recv.y};
+          *(uint4*)(orow + (odd ? i1 - 4 : i0)) = o;
+        }
+        if constexpr (MAXJ & 1) {
+          const int i = lane * 4 + (MAXJ - 1) * 256;
+          *(uint2*)(orow + i) = pack4h<OutT>((v[MAXJ - 1] - mean) * rstd * *(const f32x4_t*)(gamma + i) + *(const f32x4_t*)(beta + i));
+        }
+        goto next_row;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int i = lane * 4 + j * 256;
+      if (i < D) store4<OutT>(orow + i, (v[j] - mean) * rstd * *(const f32x4_t*)(gamma + i) + *(const f32x4_t*)(beta + i));
+    }
+  next_row:
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) v[j] = nx[j];
+  }
+}
+
 template <class OutT>
 void launch_ln(const float* x, const float* g, const float* b, OutT* out, int M, int D, float eps, hipStream_t s) {
-  dim3 grid((M + 3) / 4), block(256);
   const int mj = (D + 255) / 256;
-  if (mj <= 1) hipLaunchKernelGGL((layernorm_kernel<OutT, 1>), grid, block, 0, s, x, g, b, out, M, D, eps);
-  else if (mj <= 2) hipLaunchKernelGGL((layernorm_kernel<OutT, 2>), grid, block, 0, s, x, g, b, out, M, D, eps);
-  else if (mj <= 4) hipLaunchKernelGGL((layernorm_kernel<OutT, 4>), grid, block, 0, s, x, g, b, out, M, D, eps);
-  else if (mj <= 5) hipLaunchKernelGGL((layernorm_kernel<OutT, 5>), grid, block, 0, s, x, g, b, out, M, D, eps);
-  else hipLaunchKernelGGL((layernorm_kernel<OutT, 8>), grid, block, 0, s, x, g, b, out, M, D, eps);
+  // all waves resident at once: <= 16 waves per CU (4 workgroups of 256), every wave ceil(M / waves) rows
+  const int cus = hm_device_cu_count() > 0 ? hm_device_cu_count() : 256;
+  const int max_waves = cus * 16;
+  const int rpw = (M + max_waves - 1) / max_waves;
+  const int waves = (M + rpw - 1) / rpw;
+  dim3 grid((waves + 3) / 4), block(256);
+  if (mj <= 1) hipLaunchKernelGGL((layernorm_rows_kernel<OutT, 1>), grid, block, 0, s, x, g, b, out, M, D, eps, rpw);
+  else if (mj <= 2) hipLaunchKernelGGL((layernorm_rows_kernel<OutT, 2>), grid, block, 0, s, x, g, b, out, M, D, eps, rpw);
+  else if (mj <= 4) hipLaunchKernelGGL((layernorm_rows_kernel<OutT, 4>), grid, block, 0, s, x, g, b, out, M, D, eps, rpw);
+  else if (mj <= 5) hipLaunchKernelGGL((layernorm_rows_kernel<OutT, 5>), grid, block, 0, s, x, g, b, out, M, D, eps, rpw);
+  else hipLaunchKernelGGL((layernorm_rows_kernel<OutT, 8>), grid, block, 0, s, x, g, b, out, M, D, eps, rpw);
 }
 
 __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ vec, float* __restrict__ out,

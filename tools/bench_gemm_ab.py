@@ -14,10 +14,14 @@ from hamer_yolo_amd import ops
 variants = [int(v) for v in os.environ.get("VARIANTS", "0,8").split(",")]      # v >= 100: default variant with group_m = v - 100
 rounds, reps = int(os.environ.get("ROUNDS", 6)), int(os.environ.get("REPS", 5))
 M = int(os.environ.get("BATCH", 64)) * 192
+DT = torch.float16 if os.environ.get("DTYPE", "fp16") == "fp16" else torch.bfloat16
+ONLY = [n for n in os.environ.get("SHAPES", "").split(",") if n]
 dev = "cuda"
 torch.manual_seed(0)
 shapes = [("qkv", 1280, 3840, L.HM_EPI_STORE), ("proj", 1280, 1280, L.HM_EPI_RESID_F32), ("fc1", 1280, 5120, L.HM_EPI_GELU),
-          ("fc2", 5120, 1280, L.HM_EPI_RESID_F32)]
+          ("fc2", 5120, 1280, L.HM_EPI_RESID_F32), ("kv", 1280, 6144, L.HM_EPI_STORE)]
+if ONLY:
+    shapes = [sh for sh in shapes if sh[0] in ONLY]
 lib = L.load()
 res = {}
 
@@ -30,11 +34,11 @@ def setv(v):
 
 
 for (name, K, N, epi) in shapes:
-    x = torch.randn(M, K, device=dev).bfloat16()
-    w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    x = torch.randn(M, K, device=dev).to(DT)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(DT)
     b = torch.randn(N, device=dev)
     f32 = epi == L.HM_EPI_RESID_F32
-    out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else DT)
     r = torch.randn(M, N, device=dev) if f32 else None
     times = {v: [] for v in variants}
     for v in variants:                        # warm

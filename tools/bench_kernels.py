@@ -39,7 +39,7 @@ def timeit(name, fn, flops=None, nbytes=None):
 
 
 variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
-for dt in (torch.bfloat16,):
+for dt in (torch.float16,):
   for variant in variants:
     L.check(L.load().hm_gemm_set_variant(variant))
     print(f"--- gemm tile variant {variant}", flush=True)
@@ -54,6 +54,6 @@ for dt in (torch.bfloat16,):
 
 x = torch.randn(M, 1280, device=dev)
 g, bb = torch.randn(1280, device=dev), torch.randn(1280, device=dev)
-timeit("layernorm 12288x1280 -> bf16", lambda: ops.layernorm(x, g, bb, 1e-6, torch.bfloat16), nbytes=M * 1280 * 6)
-qkv = rnd(M, 3840)
+timeit("layernorm 12288x1280 -> fp16", lambda: ops.layernorm(x, g, bb, 1e-6, torch.float16), nbytes=M * 1280 * 6)
+qkv = rnd(M, 3840, dt=torch.float16)
 timeit("attention B64 H16 T192 d80", lambda: ops.vit_attention(qkv, 64, 192, 16, 80, 80 ** -0.5), flops=64 * 16 * 4.0 * 192 * 192 * 80, nbytes=M * 5120 * 2)
