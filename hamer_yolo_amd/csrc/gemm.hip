@@ -813,6 +813,203 @@ int launch_rs(const KArgs& g, hipStream_t s) {
   return hm_check_launch("hm_gemm");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of gemm_x3_kernel for the 16-bit store epilogues (qkv, fc1, to_kv: 3-5 tiles per CU at B = 64).
+// Launched tile by tile, every tile pays its own start-up in series with everything else on its CU -- address set-up,
+// the first HBM/L2 round trip of its operands (nothing to overlap it with: one workgroup per CU), the wait for its
+// result stores to be acknowledged before the wave may end, the dispatch of the next workgroup: ~11 us per 32 us K loop
+// at K = 1280.  Here one workgroup per CU walks its tiles (the same XCD-contiguous order the dispatcher produced) and the
+// LDS-DMA pipeline never stops: step t of the concatenated (tile, k-step) sequence issues W(t+1) and X(t+2) whether or
+// not they belong to the next tile, so a tile's first operands land during the previous tile's last K-steps and
+// epilogue, and its stores retire under the next tile's K loop.
+//   LDS: X ring of 3 slots + W ring of 2 (all 160 KB), slot = step % 3 / step & 1 across tiles.  The epilogue stages
+//   through the X slot the tile's LAST step read (4 KB per wave: 32-row half-strips) and keeps the bias in that step's W
+//   slot; the copies in flight meanwhile target the other slots, and those two are first written again after the next
+//   step's barrier.
+//   vmcnt: loads, stores and LDS-DMA count together, in issue order -- waiting for an operation waits for every older
+//   one.  So the epilogue contains NO load (a wait for it would drain the stores before it: the bias travels through two
+//   registers requested at the top of the tile) and exactly 16 stores per wave (interior tiles only: the launcher
+//   guarantees M, N multiples of 256), issued after the copies W(t+1), X(t+2) of the last step; the first step of the next
+//   tile therefore waits vmcnt(16 + 4): everything but those stores and X(t+2).  An extra vector-memory operation
+//   anywhere (a spill, the next tile's bias request) only makes a counted wait stricter, never looser.
+template <class T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
+  static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
+  constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
+  constexpr int TILE_BYTES = 256 * ROWB;                               // 32 KB
+  constexpr int XRING = 0, WRING = 3 * TILE_BYTES;
+  constexpr int XI = 4, WI = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using vec8 = typename T::vec8;
+  using elem = typename T::elem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = g.N >> 8, tiles_m = g.M >> 8, tiles = tiles_m * tiles_n;
+  // this workgroup's tiles: XCD `blockIdx & 7` owns a contiguous run of tile ids (as xcd_remap deals them), its G/8
+  // workgroups take them round robin -- the order the dispatcher gave the one-tile workgroups
+  const int G = gridDim.x, xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per = G >> 3;
+  const int tq = tiles >> 3, tr = tiles & 7;
+  const int run_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_len = tq + (xcd < tr ? 1 : 0);
+  const int my = li < run_len ? (run_len - li + per - 1) / per : 0;
+  if (my == 0) return;
+  const int nk = g.K / 64, S = my * nk;
+  const int wr = wave / WN, wc = wave % WN;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+
+  const int srow = lane >> 3, swz = (lane & 7) ^ (srow & 7);
+  unsigned xoff[XI], woff[WI];                        // lane part of the source address; the tile origin rides in the scalar base
+#pragma unroll
+  for (int i = 0; i < XI; ++i) xoff[i] = (unsigned)(wave * XI * 8 + i * 8 + srow) * (unsigned)(g.ldx * 2) + swz * 16;
+#pragma unroll
+  for (int i = 0; i < WI; ++i) woff[i] = (unsigned)(wave * WI * 8 + i * 8 + srow) * (unsigned)(g.ldw * 2) + swz * 16;
+  auto origin = [&](int ti, int& m0, int& n0) {
+    int tm, tn;
+    tile_coords(run_lo + li + ti * per, tiles_m, tiles_n, g.group_m, tm, tn);
+    m0 = tm << 8; n0 = tn << 8;
+  };
+  auto dma_x = [&](int slot, const char* base) {
+    char* l = smem + XRING + slot * TILE_BYTES + wave * XI * 1024;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) glds16_hidden_s(base, xoff[i], l + i * 1024);
+  };
+  auto dma_w = [&](int slot, const char* base) {
+    char* l = smem + WRING + slot * TILE_BYTES + wave * WI * 1024;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) glds16_hidden_s(base, woff[i], l + i * 1024);
+  };
+  // cursors over the concatenated step sequence: X runs two steps ahead of the MFMAs, W one
+  int xti = 0, xkt = 0, wti = 0, wkt = 0, m0, n0;
+  origin(0, m0, n0);
+  const char* xbase = X + (size_t)m0 * g.ldx * 2;
+  const char* wbase = W + (size_t)n0 * g.ldw * 2;
+  auto next_x = [&]() {
+    if (++xkt == nk) {
+      xkt = 0;
+      if (++xti < my) { int a, b; origin(xti, a, b); xbase = X + (size_t)a * g.ldx * 2; }
+    }
+  };
+  auto next_w = [&]() {
+    if (++wkt == nk) {
+      wkt = 0;
+      if (++wti < my) { int a, b; origin(wti, a, b); wbase = W + (size_t)b * g.ldw * 2; }
+    }
+  };
+
+  f32x4_t acc[NI][MI];
+  const int frow = lane & 15, fsw = lane & 7, fch = lane >> 4;
+  auto substep = [&](int xslot, int wslot, int ks) {
+    const char* lx = smem + XRING + xslot * TILE_BYTES;
+    const char* lw = smem + WRING + wslot * TILE_BYTES;
+    const int coff = ((ks * 4 + fch) ^ fsw) * 16;
+    vec8 wf[NI], xf[MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue: X(0), W(0), X(1) (nk >= 2)
+  dma_x(0, xbase); next_x();
+  dma_w(0, wbase); next_w();
+  dma_x(1, xbase + (size_t)xkt * ROWB); next_x();
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+
+  int gs = 0, xs = 0;                                  // global step, its X slot (gs % 3); W slot = gs & 1
+  for (int ti = 0; ti < my; ++ti) {
+    if (ti > 0) origin(ti, m0, n0);
+    // this wave's 128 bias values, two per lane: requested now, first touched at the top of the tile's last K-step (so the
+    // compiler's wait for them sits where nothing but already-needed copies is outstanding), moved to LDS after the loop
+    float bias_lo = 0.f, bias_hi = 0.f;
+    if (g.bias) { bias_lo = g.bias[n0 + wc * 128 + lane]; bias_hi = g.bias[n0 + wc * 128 + 64 + lane]; }
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int xs_last = 0, ws_last = 0;
+    for (int kt = 0; kt < nk; ++kt, ++gs) {
+      if (gs > 0) {
+        if (kt == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");          // 16 epilogue stores + X(gs+1) may stay in flight
+        else if (gs + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // X(gs+1)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                    // step gs complete in LDS; everyone is done with step gs-1's slots (and epilogue)
+      if (kt == nk - 1) asm volatile("" :: "v"(bias_lo), "v"(bias_hi));
+      const int ws = gs & 1, xs2 = xs == 0 ? 2 : xs - 1;
+      substep(xs, ws, 0);
+      if (gs + 1 < S) { dma_w(ws ^ 1, wbase + (size_t)wkt * ROWB); next_w(); }   // W first, then X: the counted waits rely on this order
+      if (gs + 2 < S) { dma_x(xs2, xbase + (size_t)xkt * ROWB); next_x(); }
+      substep(xs, ws, 1);
+      xs_last = xs; ws_last = ws;
+      xs = xs == 2 ? 0 : xs + 1;
+    }
+    __builtin_amdgcn_s_barrier();                      // the last step's two slots are free: epilogue staging
+
+    // ---- epilogue: 64 x 128 per wave = 4 column groups of 32 x 2 half-strips of 32 rows, each through 4 KB of LDS (all
+    // eight waves inside the last step's X slot; the wave's 128 bias values wait in 512 B of the last step's W slot).
+    // No vector-memory instruction here but the stores: exactly 16 per wave.
+    float* cb = (float*)(smem + WRING + ws_last * TILE_BYTES + wave * 512);
+    cb[lane] = bias_lo; cb[64 + lane] = bias_hi;                       // wave-private: written and read by this wave only
+    char* wl = smem + XRING + xs_last * TILE_BYTES + wave * 4096;
+    const int arow = lane & 15, apiece = lane >> 4, row0 = lane >> 2, j = lane & 3;
+    const int mb = m0 + wr * 64, nb = n0 + wc * 128;
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+      const f32x4_t b0 = *(const f32x4_t*)(cb + cg * 32 + 8 * j), b1 = *(const f32x4_t*)(cb + cg * 32 + 8 * j + 4);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            const int row = mm * 16 + arow;
+            *(f32x4_t*)(wl + row * 128 + (((nl * 4 + apiece) ^ (row & 7)) << 4)) = acc[cg * 2 + nl][half * 2 + mm];
+          }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 16 + row0, sw = row & 7;
+          const f32x4_t v0 = *(const f32x4_t*)(wl + row * 128 + (((2 * j) ^ sw) << 4));
+          const f32x4_t v1 = *(const f32x4_t*)(wl + row * 128 + (((2 * j + 1) ^ sw) << 4));
+          vec8 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a = __fadd_rn(v0[q], b0[q]), b = __fadd_rn(v1[q], b1[q]);           // as the one-tile kernels round
+            if constexpr (EPI == HM_EPI_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0]; b = gq[1]; }
+            o[q] = (elem)a; o[4 + q] = (elem)b;
+          }
+          *(vec8*)((elem*)g.C + (size_t)(mb + half * 32 + row) * g.ldc + nb + cg * 32 + 8 * j) = o;
+        }
+      }
+    }
+  }
+}
+
+template <class T, int EPI>
+int launch_px(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 5 * 256 * 128;
+  auto kern = gemm_px_kernel<T, EPI>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
+  const int tiles = (g.M >> 8) * (g.N >> 8);
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int grid = (tiles < cus ? tiles : cus) & ~7;               // one workgroup per CU, a multiple of the 8 XCDs
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);
+  return hm_check_launch("hm_gemm");
+}
+
+// what gemm_px_kernel requires: whole 256 x 256 tiles, at least two K-steps, 16-byte output rows, 32-bit lane offsets
+bool px_ok(const KArgs& g) {
+  return g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 128 && (g.ldc & 7) == 0 && (g.M >> 8) * (g.N >> 8) >= 8 &&
+         256ull * g.ldx * 2 < (1ull << 32) && 256ull * g.ldw * 2 < (1ull << 32) && (((uintptr_t)g.C) & 15) == 0;
+}
+
 // partial (sum, sum of squares) per 64 columns [P][M][2] -> (mean, rstd) per row [M][2]
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ fin, int M, int P,
                                                           float invD, float eps) {
@@ -868,6 +1065,11 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
     case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
     case 25: return launch_cfg<T, EPI, 4, 2, 4, 10, 2, false, 64, 2>(g, s, "hm_gemm"); // 256x320, waves 4x2 (64x160 each), 2 stages (144 KB)
+    case 26:                                                                           // persistent 256x256 (gemm_px_kernel), else as 24
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
+        if (px_ok(g)) return launch_px<T, EPI>(g, s);
+      }
+      [[fallthrough]];
     case 24:                                                                           // X two K-steps ahead in a 3-slot ring (gemm_x3_kernel)
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
         if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_rs<T, EPI>(g, s);   // 32-bit lane offsets
@@ -897,7 +1099,7 @@ bool variant_ok(int v) {
 #ifdef HM_ABLATIONS
   if (v == 14 || v == 15 || v == 18 || v == 20) return true;
 #endif
-  return (v >= 0 && v <= 11) || (v >= 21 && v <= 25);
+  return (v >= 0 && v <= 11) || (v >= 21 && v <= 27);
 }
 
 int pick_variant(const KArgs& g) {
@@ -906,14 +1108,20 @@ int pick_variant(const KArgs& g) {
     const int v = e ? atoi(e) : -1;
     g_variant = variant_ok(v) ? v : -1;
   }
-  if (g_variant >= 0) return g_variant;
+  if (g_variant >= 0 && g_variant != 27) return g_variant;
   if (g.M < 1024 || g.N < 512) return 0;
   // the 256x256 tile only when its tiles fill whole rounds of the 256 CUs: at 16-32 hands proj / fc2 have 60-120 of them
   // and qkv 180-360, and the 128x128 tile (2 workgroups per CU) is 20-60 % faster over the forward
   const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), rounds = (tiles + 255) / 256;
   if (tiles * 100 < rounds * 256 * 85) return 0;
-  return 24;     // X two K-steps ahead (gemm_x3_kernel) for the store / gelu / residual epilogues, else the variant-10 tile:
-                 // -2 % per GEMM in isolation, +0.5 % hands/s with two batches in flight
+  // 256x320 where it divides N and its tiles make fuller rounds (fc1 at B = 64: 768 tiles = 3.0 rounds against 960 = 3.75,
+  // and 10 % fewer operand bytes per flop: 168 us against 181).  (Variant 27 = this choice without that rule, for A/B runs.)
+  if (g_variant != 27 && g.N % 320 == 0 && g.M % 256 == 0) {
+    const int t320 = (g.M / 256) * (g.N / 320), r320 = (t320 + 255) / 256;
+    if (t320 * rounds * 100 > tiles * r320 * 103) return 25;
+  }
+  return 26;     // persistent 256x256 (gemm_px_kernel) for the 16-bit store epilogues on whole tiles; otherwise the
+                 // one-tile kernel with X two K-steps ahead (gemm_x3_kernel, variant 24), else the variant-10 tile
 }
 
 template <class T>
@@ -972,7 +1180,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..25");
+  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..27");
   g_variant = v;
   return HM_OK;
 }

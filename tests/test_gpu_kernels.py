@@ -84,6 +84,68 @@ def test_gemm_deep_prefetch_variant_exact(dt):
         lib.hm_gemm_set_variant(-1)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_persistent_kernel_exact(dt):
+    """gemm_px_kernel (variant 26: one workgroup per CU walks its tiles, the LDS-DMA pipeline runs across tile boundaries,
+    hand-counted vmcnt over copies AND the epilogue's stores) on exact-integer data: bit-exact against torch for 2 and many
+    K-steps, with and without bias, tile counts below / equal to / far above the CU count (1..6 tiles per workgroup, uneven
+    shares), repeated launches as a race screen; the GELU epilogue bit-equal to the one-tile kernel's (variant 24)."""
+    lib = L.load()
+    try:
+        for (M, N, K) in ((2048, 256, 128), (2304, 2560, 128), (4096, 4096, 192), (2560, 10240, 128), (12288, 3840, 1280), (5120, 5120, 64 * 7)):
+            x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+            w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+            bias = (torch.arange(N) % 9 - 4).float()
+            xd, wd, bd = x.to(DEV, dt), w.to(DEV, dt), bias.to(DEV)
+            ref = (xd.float() @ wd.float().t()).cpu()                     # exact in fp32: small integers
+            L.check(lib.hm_gemm_set_variant(26))
+            for rep in range(3):
+                o = ops.gemm(xd, wd, bd, L.HM_EPI_STORE)
+                assert torch.equal(o.float().cpu(), (ref + bias).to(dt).float()), (M, N, K, rep)
+            o = ops.gemm(xd, wd, None, L.HM_EPI_STORE)
+            assert torch.equal(o.float().cpu(), ref.to(dt).float()), (M, N, K, "no bias")
+            # random operands, GELU: the same rounding order as the one-tile kernel, so bit-equal to it
+            xr = _u("px", (M, K), 1.0, seed=M).to(DEV, dt)
+            wr = _u("pw", (N, K), 0.05, seed=N).to(DEV, dt)
+            g26 = [ops.gemm(xr, wr, bd, L.HM_EPI_GELU) for _ in range(2)]
+            s26 = ops.gemm(xr, wr, bd, L.HM_EPI_STORE)
+            L.check(lib.hm_gemm_set_variant(24))
+            g24 = ops.gemm(xr, wr, bd, L.HM_EPI_GELU)
+            s24 = ops.gemm(xr, wr, bd, L.HM_EPI_STORE)
+            assert torch.equal(g26[0], g24) and torch.equal(g26[1], g24) and torch.equal(s26, s24), (M, N, K)
+        # shapes the persistent kernel does not take (ragged M / N, one K-step) fall back to the one-tile kernels
+        L.check(lib.hm_gemm_set_variant(26))
+        for (M, N, K) in ((300, 260, 64), (2048, 2048, 64), (1000, 1284, 192)):
+            x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+            w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+            o = ops.gemm(x.to(DEV, dt), w.to(DEV, dt), None, L.HM_EPI_STORE)
+            assert torch.equal(o.float().cpu(), (x @ w.t()).to(dt).float()), (M, N, K)
+    finally:
+        lib.hm_gemm_set_variant(-1)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_256x320_tile_exact(dt):
+    """Variant 25 (256x320 tile, the fc1 choice at B = 64) on exact-integer data, ragged and whole shapes, every epilogue
+    family it can be given: 16-bit store, fp32 out, fp32 residual."""
+    lib = L.load()
+    try:
+        L.check(lib.hm_gemm_set_variant(25))
+        for (M, N, K) in ((300, 260, 64), (513, 388, 128), (1000, 1284, 448), (768, 5120, 1280), (2304, 640, 192)):
+            x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+            w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+            bias = (torch.arange(N) % 9 - 4).float()
+            resid = ((torch.arange(M * N).reshape(M, N) * 3) % 11 - 5).float()
+            xd, wd, bd, rd = x.to(DEV, dt), w.to(DEV, dt), bias.to(DEV), resid.to(DEV)
+            ref = x @ w.t() + bias
+            assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_F32).cpu(), ref), (M, N, K)
+            assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd).cpu(), ref + resid), (M, N, K)
+            if N % 8 == 0:
+                assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_STORE).float().cpu(), ref.to(dt).float()), (M, N, K)
+    finally:
+        lib.hm_gemm_set_variant(-1)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(384, 1280, 768), (192, 3840, 1280), (200, 132, 64), (64, 6144, 1280), (1, 4, 64)])
 def test_gemm_epilogues(M, N, K, dt):
