@@ -149,16 +149,23 @@ def run_e2e(args, dev, dtype):
                       "gflop_per_frame": round(61.9 + hands / n_frames * 251.03, 1)}), flush=True)
 
 
+def latest_profile(suffix: str):
+    """profiles/rNN_<suffix> of the newest round that has one (the PMC passes are collected per round, tools/collect_profiles.sh)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else None
+
+
 def mfma_busy_pmc(cfg):
     """MFMA-pipe busy fraction of the GEMM launches of one step from the committed PMC pass (rocprofv3 --pmc
     SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/pmc_shapes.py; profiles/r01_pmc_mfma_busy.json), cycle-weighted."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_mfma_busy.json")
-    if not os.path.exists(path):
+    path = latest_profile("pmc_mfma_busy.json")
+    if path is None:
         return None
     t = json.load(open(path))
     w = {"patch": 1, "qkv": cfg.vit.depth, "proj": cfg.vit.depth, "fc1": cfg.vit.depth, "fc2": cfg.vit.depth, "kv": 1}
     busy = sum(t[k]["SQ_VALU_MFMA_BUSY_CYCLES"] * n for k, n in w.items())
-    cyc = sum(t[k]["shader_cycles"] * 1024 * n for k, n in w.items())
+    cyc = sum(t[k]["shader_cycles"] * 1024 * n for k, n in w.items())      # (1024 SIMDs)
     return round(busy / cyc, 4)
 
 
@@ -341,12 +348,12 @@ def main():
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         # HBM-side bytes per GEMM launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # runs over tools/pmc_shapes.py, gfx950 FETCH_SIZE x2 correction; tools/pmc_parse.py), weighted by launches per step
-        traffic, traffic_src = None, os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(traffic_src) and B == 64:
+        traffic, traffic_src = None, latest_profile("pmc_traffic.json")
+        if traffic_src is not None and B == 64:
             t = json.load(open(traffic_src))
             w = {"patch": 1, "qkv": cfg.vit.depth, "proj": cfg.vit.depth, "fc1": cfg.vit.depth, "fc2": cfg.vit.depth, "kv": 1}
             traffic = round(sum(t[k]["hbm_bytes"] * n for k, n in w.items()) / sum(w.values()))
-        kernel_name, peak = "gemm_x3_kernel / gemm_tn_kernel (the 256x256 MFMA GEMM, all epilogues)", PEAK_BF16_TFLOPS
+        kernel_name, peak = "gemm_px_kernel / gemm_x3_kernel / gemm_tn_kernel (the 256x256 MFMA GEMM, all epilogues)", PEAK_BF16_TFLOPS
         if args.dtype == "fp8":      # dominant kernel = gemm_fp8_kernel: price its launches against the fp8 peak
             f8 = [(M_, N_, K_, ms_) for (kd, e_, M_, N_, K_, ms_) in prof.records if kd == "gemm" and e_ >= 16]
             achieved = sum(2.0 * a * b * c for a, b, c, _ in f8) / (sum(t for *_, t in f8) * 1e-3) / 1e12
@@ -354,7 +361,7 @@ def main():
         res["roofline"] = {
             "kernel": kernel_name, "bound": "mfma", "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_note": "bytes per launch beyond L2 (FETCH_SIZE*2 + WRITE_SIZE, PMC pass committed under profiles/; Infinity-Cache hits included), "
+            "traffic_note": "bytes per launch beyond L2 (FETCH_SIZE*2 + WRITE_SIZE, PMC pass %s; Infinity-Cache hits included), " % (os.path.basename(traffic_src) if traffic_src else "absent") +
                             "algorithmic operand+result bytes per launch: %d" % round(sum(
                                 (2 * (M_ * K_ + N_ * K_) + M_ * N_ * {2: 8, 5: 10}.get(e_, 2)) for (_, e_, M_, N_, K_, _) in
                                 [r for r in prof.records if r[0] == "gemm"]) / n_gemm),

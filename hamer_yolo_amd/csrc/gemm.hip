@@ -1099,7 +1099,7 @@ bool variant_ok(int v) {
 #ifdef HM_ABLATIONS
   if (v == 14 || v == 15 || v == 18 || v == 20) return true;
 #endif
-  return (v >= 0 && v <= 11) || (v >= 21 && v <= 27);
+  return (v >= 0 && v <= 11) || (v >= 21 && v <= 26);
 }
 
 int pick_variant(const KArgs& g) {
@@ -1108,20 +1108,16 @@ int pick_variant(const KArgs& g) {
     const int v = e ? atoi(e) : -1;
     g_variant = variant_ok(v) ? v : -1;
   }
-  if (g_variant >= 0 && g_variant != 27) return g_variant;
+  if (g_variant >= 0) return g_variant;
   if (g.M < 1024 || g.N < 512) return 0;
   // the 256x256 tile only when its tiles fill whole rounds of the 256 CUs: at 16-32 hands proj / fc2 have 60-120 of them
   // and qkv 180-360, and the 128x128 tile (2 workgroups per CU) is 20-60 % faster over the forward
   const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), rounds = (tiles + 255) / 256;
   if (tiles * 100 < rounds * 256 * 85) return 0;
-  // 256x320 where it divides N and its tiles make fuller rounds (fc1 at B = 64: 768 tiles = 3.0 rounds against 960 = 3.75,
-  // and 10 % fewer operand bytes per flop: 168 us against 181).  (Variant 27 = this choice without that rule, for A/B runs.)
-  if (g_variant != 27 && g.N % 320 == 0 && g.M % 256 == 0) {
-    const int t320 = (g.M / 256) * (g.N / 320), r320 = (t320 + 255) / 256;
-    if (t320 * rounds * 100 > tiles * r320 * 103) return 25;
-  }
   return 26;     // persistent 256x256 (gemm_px_kernel) for the 16-bit store epilogues on whole tiles; otherwise the
-                 // one-tile kernel with X two K-steps ahead (gemm_x3_kernel, variant 24), else the variant-10 tile
+                 // one-tile kernel with X two K-steps ahead (gemm_x3_kernel, variant 24), else the variant-10 tile.
+                 // Measured at B = 64, fp16 (interleaved A/B, us per launch): fc1 172 (24) / 164 (25: 256x320, 3.0 rounds
+                 // and 10 % fewer operand bytes per flop) / 162 (26); kv 181 / 180 / 174; qkv 119 / 143 / 119.
 }
 
 template <class T>
@@ -1180,7 +1176,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..27");
+  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..26");
   g_variant = v;
   return HM_OK;
 }

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round profile collection on the GPU box (run from the repo root through gpurun):
+#   1. rocprofv3 --kernel-trace --stats of the contract bench command      -> gpurun_out/prof_$TAG/
+#   2. three separate PMC passes over tools/pmc_shapes.py (one counter set each; never combined with trace domains)
+#      FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE   -> gpurun_out/pmc_$TAG/{fetch,write,mfma}
+#   3. tools/pmc_parse.py                                                   -> gpurun_out/pmc_$TAG/*.json
+# Copy what should be judged into profiles/ afterwards (gpurun_out/ is scratch).
+set -o pipefail
+TAG=${1:-r02}
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT/prof_$TAG $OUT/pmc_$TAG
+rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o ${TAG} --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_$TAG/bench_under_rocprof.log 2>&1 || exit 1
+tail -c 300 $OUT/prof_$TAG/bench_under_rocprof.log
+for pass in fetch write mfma; do
+  case $pass in
+    fetch) PMC="FETCH_SIZE" ;;
+    write) PMC="WRITE_SIZE" ;;
+    mfma) PMC="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" ;;
+  esac
+  rocprofv3 --pmc $PMC -d $OUT/pmc_$TAG/$pass -o $pass --output-format csv -- python3 tools/pmc_shapes.py > $OUT/pmc_$TAG/$pass.log 2>&1 || exit 1
+  echo "pmc pass $pass done"
+done
+F=$(find $OUT/pmc_$TAG/fetch -name '*counter_collection.csv' | head -1)
+W=$(find $OUT/pmc_$TAG/write -name '*counter_collection.csv' | head -1)
+Mf=$(find $OUT/pmc_$TAG/mfma -name '*counter_collection.csv' | head -1)
+python3 tools/pmc_parse.py "$F" "$W" "$Mf" $OUT/pmc_$TAG/${TAG}_pmc_traffic.json $OUT/pmc_$TAG/${TAG}_pmc_mfma_busy.json
+cp "$F" $OUT/pmc_$TAG/fetch_size_counter_collection.csv; cp "$W" $OUT/pmc_$TAG/write_size_counter_collection.csv; cp "$Mf" $OUT/pmc_$TAG/mfma_busy_counter_collection.csv
