@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhamer_hip.so")
-SOURCES = ["status.hip", "gemm.hip", "norm.hip", "attention.hip", "patch.hip", "decoder.hip", "mano.hip", "forward.hip", "prof.hip", "yolo.hip"]
+SOURCES = ["status.hip", "gemm.hip", "norm.hip", "attention.hip", "patch.hip", "decoder.hip", "mano.hip", "tome.hip", "forward.hip", "prof.hip", "yolo.hip"]
 
 
 def _stale() -> bool:

@@ -12,6 +12,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
   size_t patches, x, h, qkv, att, mlp, kv, xd, hd, t1, t2, head, stats, rowstats, hs, mlps, atts, partials, total;
+  size_t x2, tsize, tmetric, tindex;          // token merging: second residual stream, sizes [2][M], metric [M][80], indices
   int ksplit_proj, ksplit_fc2;
 };
 
@@ -56,6 +57,14 @@ Layout make_layout(const hm_hamer_weights& w, int B) {
   L.ksplit_fc2 = pick_split_k((int)M, (int)D, w.mlp_dim);
   const int smax = L.ksplit_proj > L.ksplit_fc2 ? L.ksplit_proj : L.ksplit_fc2;
   L.partials = o; o += smax > 1 ? align256((size_t)smax * M * D * 4) : 0;
+  L.x2 = L.tsize = L.tmetric = L.tindex = 0;
+  if (w.tome_r) {
+    L.x2 = o; o += align256(M * D * 4);
+    L.tsize = o; o += align256(2 * M * 4);
+    L.tmetric = o; o += align256(M * (D / w.heads) * 4);
+    L.tindex = o; o += align256(hm_tome_index_bytes(B));
+    L.ksplit_proj = L.ksplit_fc2 = 1;
+  }
   L.total = o;
   return L;
 }
@@ -150,6 +159,48 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
   HM_TRY(hm_patch_im2col(img, ws + L.patches, B, w->img_h, w->img_w_full, w->win_x0, w->win_w, w->patch, w->pad, dt, stream));
   const float scale = 1.0f / sqrtf((float)(D / w->heads));
   void* tok = out->tokens ? out->tokens : h;
+  int ctx_tokens = tokens;                              // tokens per crop the decoder attends over
+  if (w->tome_r) {
+    // token-merging variant (selective_vit_adapter.py ToMeBlock.forward :210-235): the token count T shrinks after the
+    // attention of every block, the same for every crop, so all buffers stay compact [B * T][.] and only M changes
+    if (fp8 || D / w->heads != 80) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: token merging needs the 16-bit path and head_dim 80");
+    int T = tokens;
+    float* xc = x;                                      // current / spare residual stream
+    float* xn = (float*)(ws + L.x2);
+    float *szc = nullptr, *szn = (float*)(ws + L.tsize);
+    auto gemm_m = [&](int Mi, const void* X, int ldx, const void* W, int K, int N, void* C, int ldc, const float* bias, int epi,
+                      const float* resid, int ldr, int rmod) {
+      hm_gemm_args g{};
+      g.X = X; g.W = W; g.C = C; g.bias = bias; g.resid = resid;
+      g.M = Mi; g.N = N; g.K = K; g.ldx = ldx; g.ldw = K; g.ldc = ldc; g.ldr = ldr; g.resid_mod = rmod;
+      g.epilogue = epi; g.dtype = dt;
+      return hm_gemm(&g, stream);
+    };
+    HM_TRY(gemm_m(M, ws + L.patches, kpe, w->patch_w, kpe, D, xc, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
+    for (int i = 0; i < w->depth; ++i) {
+      const hm_vit_block& b = w->blocks[i];
+      int Mi = B * T;
+      HM_TRY(hm_layernorm(xc, b.ln1_g, b.ln1_b, h, dt, Mi, D, w->vit_eps, stream));
+      HM_TRY(gemm_m(Mi, h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
+      HM_TRY(hm_tome_attention(qkv, szc, att, B, T, w->heads, D / w->heads, scale, dt, stream));
+      HM_TRY(gemm_m(Mi, att, D, b.proj_w, D, D, xc, D, b.proj_b, HM_EPI_RESID_F32, xc, D, 0));
+      int r = w->tome_r[i] < T / 2 ? w->tome_r[i] : T / 2;          // r = min(r, t // 2) (:42)
+      if (r > 0) {
+        HM_TRY(hm_tome_merge(qkv, xc, szc, xn, szn, (float*)(ws + L.tmetric), (int*)(ws + L.tindex), B, T, r, w->heads,
+                             D / w->heads, D, dt, stream));
+        float* t0 = xc; xc = xn; xn = t0;
+        float* s_old = szc;
+        szc = szn;
+        szn = s_old ? s_old : (float*)(ws + L.tsize) + M;            // the two halves of the size buffer alternate
+        T -= r; Mi = B * T;
+      }
+      HM_TRY(hm_layernorm(xc, b.ln2_g, b.ln2_b, h, dt, Mi, D, w->vit_eps, stream));
+      HM_TRY(gemm_m(Mi, h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0));
+      HM_TRY(gemm_m(Mi, mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, xc, D, b.fc2_b, HM_EPI_RESID_F32, xc, D, 0));
+    }
+    HM_TRY(hm_layernorm(xc, w->last_g, w->last_b, tok, dt, B * T, D, w->vit_eps, stream));
+    ctx_tokens = T;
+  } else {
   if (fold) HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_LN, w->pos, D, tokens, w->blocks[0].ln1_g));
   else HM_TRY(gemm(ws + L.patches, kpe, w->patch_w, kpe, D, x, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
   for (int i = 0; i < w->depth; ++i) {
@@ -188,10 +239,16 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
     }
   }
   if (fold || fp8) HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
+  }   // dense backbone
 
   // ---- decoder head (mano_head.py:61-95, pose_transformer.py:191-201)
   const int dim = w->dec_dim, inner = w->dec_heads * w->dec_dim_head, ldkv = w->dec_depth * 2 * inner;
-  HM_TRY(gemm(tok, D, w->kv_w, D, ldkv, kv, ldkv, nullptr, HM_EPI_STORE, nullptr, 0, 0));
+  {
+    hm_gemm_args g{};                                   // to_kv of all decoder layers over the B * ctx_tokens context rows
+    g.X = tok; g.W = w->kv_w; g.C = kv; g.M = B * ctx_tokens; g.N = ldkv; g.K = D; g.ldx = D; g.ldw = D; g.ldc = ldkv;
+    g.epilogue = HM_EPI_STORE; g.dtype = dt;
+    HM_TRY(hm_gemm(&g, stream));
+  }
   float *xd = (float*)(ws + L.xd), *hd = (float*)(ws + L.hd), *t1 = (float*)(ws + L.t1), *t2 = (float*)(ws + L.t2);
   HM_TRY(hm_broadcast_rows(w->token0, xd, B, dim, stream));
   const float dscale = 1.0f / sqrtf((float)w->dec_dim_head);
@@ -210,7 +267,7 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
     // cross-attention on the backbone tokens (pose_transformer.py:111-124)
     HM_TRY(hm_layernorm(xd, l.ln1_g, l.ln1_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));
     HM_TRY(hm_linear_f32(hd, dim, l.ca_q_w, dim, nullptr, nullptr, 0, t1, inner, B, inner, dim, 0, stream));
-    HM_TRY(hm_cross_attention(t1, kv, ldkv, i * 2 * inner, i * 2 * inner + inner, t2, B, tokens, w->dec_heads,
+    HM_TRY(hm_cross_attention(t1, kv, ldkv, i * 2 * inner, i * 2 * inner + inner, t2, B, ctx_tokens, w->dec_heads,
                               w->dec_dim_head, dscale, dt, stream));
     HM_TRY(hm_linear_f32(t2, inner, l.ca_out_w, inner, l.ca_out_b, xd, dim, xd, dim, B, dim, inner, 0, stream));
     // feed-forward (pose_transformer.py:40-52)

@@ -26,6 +26,20 @@ from .ops import mano_model_struct
 from .synth import HamerConfig
 
 
+def parse_tome_r(num_layers: int, r):
+    """Tokens to merge away per block from a constant, an (r, inflection) pair or a list -- the schedule forms of the
+    reference's ToMe patch (selective_vit_adapter.py:132-157); (8, -1) is what HAMER_INFER sets."""
+    if isinstance(r, (list,)):
+        return [int(v) for v in r] + [0] * max(0, num_layers - len(r))
+    inflect = 0.0
+    if isinstance(r, tuple):
+        r, inflect = r
+    lo = int(r * (1.0 - inflect))
+    hi = 2 * r - lo
+    step = (hi - lo) / (num_layers - 1)
+    return [int(lo + step * i) for i in range(num_layers)]
+
+
 class ForwardContext:
     """One batch in flight: its own HIP stream, workspace and output tensors (HamerEngine.contexts)."""
 
@@ -36,7 +50,7 @@ class ForwardContext:
 class HamerEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], mano: Dict[str, torch.Tensor],
                  cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.float16, fold_ln: Optional[bool] = None,
-                 fp8: Optional[bool] = None):
+                 fp8: Optional[bool] = None, token_merge=None):
         if not torch.cuda.is_available():
             raise L.HipLibraryError("HamerEngine needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = L.load()
@@ -164,6 +178,19 @@ class HamerEngine:
         w.mano = mano_model_struct(self.mano)
         w.focal_length, w.image_size = float(self.cfg.focal_length), float(self.cfg.image_size)
         w.dtype = L.HM_DTYPE_BF16 if dtype == torch.bfloat16 else L.HM_DTYPE_F16
+        # token merging (HAMER_INFER(token_merge=True), hamer.py:481-483): True = the reference's schedule r = (8, -1);
+        # an int, an (r, inflection) pair or a per-block list are parsed as selective_vit_adapter.py:132-157 does
+        self.tome_r = None
+        self.ctx_tokens = v.tokens
+        if token_merge:
+            if self.fp8:
+                raise L.HipLibraryError("token merging runs on the 16-bit path")
+            self.tome_r = parse_tome_r(v.depth, (8, -1) if token_merge is True else token_merge)
+            self._tome_arr = (C.c_int * v.depth)(*self.tome_r)
+            w.tome_r = C.cast(self._tome_arr, C.POINTER(C.c_int))
+            self.fold_ln = False
+            for ri in self.tome_r:
+                self.ctx_tokens -= min(ri, self.ctx_tokens // 2)
         self.w = w
         self.tokens = v.tokens
         self.n_verts = int(self.mano["v_template"].shape[0])

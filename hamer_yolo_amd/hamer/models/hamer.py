@@ -63,10 +63,11 @@ def engine_config(cfg, state_dict: Dict[str, torch.Tensor]) -> synth.HamerConfig
 
 class HAMER:
     def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], mano: MANO, dtype=torch.float16,
-                 hamer_cfg: Optional[synth.HamerConfig] = None):
+                 hamer_cfg: Optional[synth.HamerConfig] = None, token_merge=False):
         self.cfg = cfg
         self.mano = mano
         self.dtype = dtype
+        self.token_merge = token_merge
         self._sd = state_dict
         self._hc = hamer_cfg or engine_config(cfg, state_dict)
         self._engine: Optional[HamerEngine] = None
@@ -80,7 +81,8 @@ class HAMER:
         if device.type != "cuda":
             raise HipLibraryError("HAMER runs on an MI355X only: the HIP hot path has no CPU fallback")
         if self._engine is None or self.device != device:
-            self._engine = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=self.dtype)
+            self._engine = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=self.dtype,
+                                       token_merge=self.token_merge or None)
             self.device = device
         return self
 
@@ -125,3 +127,13 @@ class HAMER:
         return self.forward_step(batch, train=False)
 
     __call__ = forward
+
+
+class HAMER_INFER(HAMER):
+    """The reference's inference-only model class (hamer.py:468-483): ``HAMER_INFER(cfg, init_renderer, token_merge)``;
+    with ``token_merge=True`` the backbone is ToMe-patched with ``r = (8, -1)`` (selective_vit_adapter.py).  Here the
+    weights come in explicitly (the reference builds modules and loads a state dict afterwards)."""
+
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], mano: MANO, init_renderer: bool = True, token_merge: bool = False,
+                 dtype=torch.float16, hamer_cfg: Optional[synth.HamerConfig] = None):
+        super().__init__(cfg, state_dict, mano, dtype=dtype, hamer_cfg=hamer_cfg, token_merge=(8, -1) if token_merge else False)

@@ -22,6 +22,7 @@ EXPORTS = [
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
+    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -77,7 +78,7 @@ class HamerWeights(C.Structure):
                [(n, C.c_int) for n in ("dec_dim", "dec_depth", "dec_heads", "dec_dim_head", "dec_mlp")] + \
                [("dec_eps", C.c_float), ("token0", vp), ("kv_w", vp), ("layers", C.POINTER(DecLayer)),
                 ("head_w", vp), ("head_b", vp), ("mano", ManoModel),
-                ("focal_length", C.c_float), ("image_size", C.c_float), ("dtype", C.c_int)]
+                ("focal_length", C.c_float), ("image_size", C.c_float), ("dtype", C.c_int), ("tome_r", C.POINTER(C.c_int))]
 
 
 class ConvArgs(C.Structure):
@@ -153,6 +154,10 @@ def load() -> C.CDLL:
     lib.hm_nms_workspace_bytes.restype = C.c_size_t
     lib.hm_yolo_nms.argtypes = [vp, i, i, f, f, C.c_uint, i, i, C.POINTER(LetterboxPlan), vp, vp, vp, C.c_size_t, vp]
     lib.hm_yolo_run.argtypes = [C.POINTER(YoloOp), i, vp]
+    lib.hm_tome_index_bytes.argtypes = [i]
+    lib.hm_tome_index_bytes.restype = C.c_size_t
+    lib.hm_tome_attention.argtypes = [vp, vp, vp, i, i, i, i, f, i, vp]
+    lib.hm_tome_merge.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.hm_gemm_set_variant.argtypes = [i]
     lib.hm_gemm_set_group_m.argtypes = [i]
     lib.hm_prof_begin.argtypes = [i]
@@ -162,7 +167,7 @@ def load() -> C.CDLL:
         if not hasattr(lib, name):
             raise HipLibraryError(f"{LIB_PATH} does not export {name}")
         fn = getattr(lib, name)
-        if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes", "hm_nms_workspace_bytes"):
+        if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes", "hm_nms_workspace_bytes", "hm_tome_index_bytes"):
             fn.restype = i
     _lib = lib
     return lib

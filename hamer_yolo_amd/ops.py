@@ -152,6 +152,34 @@ def vit_attention_mx8(qkv: torch.Tensor, B: int, tokens: int, heads: int, head_d
     return out8, scales
 
 
+def tome_attention(qkv: torch.Tensor, size: Optional[torch.Tensor], B: int, tokens: int, heads: int, head_dim: int,
+                   scale: float) -> torch.Tensor:
+    """ToMeAttention core: softmax(scale q k^T + log(size)) v for any tokens <= 192; size (B*tokens,) f32 or None."""
+    _dev(qkv, size)
+    assert qkv.shape == (B * tokens, 3 * heads * head_dim) and qkv.is_contiguous()
+    assert size is None or (size.shape == (B * tokens,) and size.dtype == torch.float32 and size.is_contiguous())
+    out = torch.empty(B * tokens, heads * head_dim, device=qkv.device, dtype=qkv.dtype)
+    L.check(L.load().hm_tome_attention(L.ptr(qkv), L.ptr(size), L.ptr(out), B, tokens, heads, head_dim, scale, _dt(qkv),
+                                       L.current_stream()), "hm_tome_attention")
+    return out
+
+
+def tome_merge(qkv: torch.Tensor, x: torch.Tensor, size: Optional[torch.Tensor], B: int, tokens: int, r: int, heads: int,
+               head_dim: int):
+    """Matching on the head-averaged keys of `qkv` + size-weighted merge of the fp32 stream x (B*tokens, D):
+    returns (x_out (B*(tokens-r), D), size_out (B*(tokens-r),), index (B, 3, 96) int32 = unm | src | dst)."""
+    _dev(qkv, x, size)
+    D = x.shape[1]
+    assert x.shape[0] == B * tokens and x.dtype == torch.float32 and x.is_contiguous() and qkv.is_contiguous()
+    xo = torch.empty(B * (tokens - r), D, device=x.device, dtype=torch.float32)
+    so = torch.empty(B * (tokens - r), device=x.device, dtype=torch.float32)
+    metric = torch.empty(B * tokens * head_dim, device=x.device, dtype=torch.float32)
+    index = torch.zeros(L.load().hm_tome_index_bytes(B) // 4, device=x.device, dtype=torch.int32)
+    L.check(L.load().hm_tome_merge(L.ptr(qkv), L.ptr(x), L.ptr(size), L.ptr(xo), L.ptr(so), L.ptr(metric), L.ptr(index), B, tokens, r,
+                                   heads, head_dim, D, _dt(qkv), L.current_stream()), "hm_tome_merge")
+    return xo, so, index.view(B, 3, -1), metric.view(B, tokens, head_dim)
+
+
 def patch_im2col(img: torch.Tensor, x0: int, win_w: int, patch: int, pad: int, dtype=torch.bfloat16) -> torch.Tensor:
     _dev(img)
     B, Cc, H, Wf = img.shape

@@ -128,6 +128,14 @@ def tiny_config() -> HamerConfig:
     )
 
 
+def tome_tiny_config() -> HamerConfig:
+    """tiny_config with 6 blocks: the ToMe schedule r = (8, -1) then removes [16, 12, 9, 6, 3, 0] tokens (192 -> 146)."""
+    return HamerConfig(
+        vit=ViTConfig(embed_dim=320, depth=6, heads=4),
+        dec=DecoderConfig(dim=256, depth=2, heads=4, dim_head=64, mlp_dim=256, context_dim=320),
+    )
+
+
 # --------------------------------------------------------------------------- HaMeR weights
 def hamer_state_dict(cfg: Optional[HamerConfig] = None, seed: int = 0, device="cpu",
                      bf16_representable: bool = False) -> Dict[str, torch.Tensor]:

@@ -120,6 +120,18 @@ int hm_layernorm_accum(float* x, const float* partials, int n_partials, const fl
 int hm_vit_attention(const void* qkv, void* out, int B, int tokens, int heads, int head_dim, float scale,
                      int dtype, void* stream);
 
+/* Token merging (selective_vit_adapter.py).  hm_tome_attention: ToMeAttention.forward core (:166-195) for any
+ * tokens <= 192 -- softmax(scale q k^T + log(size)) v, `size` [B*tokens] f32 or NULL (no merge yet).
+ * hm_tome_merge: the matching metric (head-averaged keys, :198), bipartite_soft_matching (:17-66: alternate tokens form
+ * the sets A / B, every A token proposes its most similar B token, the r best proposals merge) and merge_wavg (:98-113)
+ * in one call: x [B*tokens][D] f32 -> x_out [B*(tokens-r)][D], size_out [B*(tokens-r)] ([unmerged A tokens in proposal
+ * order | B tokens]).  metric_ws: B*tokens*80 floats, index_ws: hm_tome_index_bytes(B). */
+size_t hm_tome_index_bytes(int B);
+int hm_tome_attention(const void* qkv, const float* size, void* out, int B, int tokens, int heads, int head_dim, float scale,
+                      int dtype, void* stream);
+int hm_tome_merge(const void* qkv, const float* x, const float* size, float* x_out, float* size_out, float* metric_ws,
+                  int* index_ws, int B, int tokens, int r, int heads, int head_dim, int D, int dtype, void* stream);
+
 /* Same attention with MXFP8 output for an fp8 proj GEMM (bf16 qkv in).  Heads are widened from 80 to 96 columns so that
  * scale blocks of 32 never straddle two heads: out8 [B*tokens][heads*96] e4m3 bytes (columns 80..95 of every head zero),
  * out_scales [heads*3][B*tokens] E8M0.  The proj weight must use the same K order (hm_vit_block.proj_w8). */
@@ -236,6 +248,9 @@ typedef struct hm_hamer_weights {
   hm_mano_model mano;
   float focal_length, image_size;
   int dtype;
+  /* token merging (HAMER_INFER(token_merge=True), hamer.py:481-483): host array of `depth` ints, the tokens to merge away
+   * after the attention of each block (parse_r of selective_vit_adapter.py:132-157), or NULL for the dense backbone */
+  const int* tome_r;
 } hm_hamer_weights;
 
 typedef struct hm_hamer_outputs {

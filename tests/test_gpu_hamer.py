@@ -180,3 +180,87 @@ def test_batches_in_flight_do_not_interfere():
     for r, g_ in zip(ref, got):
         for n in r:
             assert torch.equal(r[n], g_[n]), n
+
+
+# ------------------------------------------------------------------------------------ token merging
+def test_tome_kernels_vs_oracle():
+    """hm_tome_attention (any token count, proportional attention) and hm_tome_merge (metric, bipartite matching, size-weighted
+    merge) against oracle/tome_ref.py on the same inputs: indices exact, values to fp32 / 16-bit rounding."""
+    from hamer_yolo_amd import ops
+    from oracle import tome_ref as T
+    B, H, d, D = 3, 4, 80, 320
+    for tokens, r, with_size in ((192, 16, False), (161, 14, True), (23, 8, True), (3, 1, True)):
+        qkv = synth.uniform("tq", (B * tokens, 3 * H * d), 1.2, seed=tokens).half()
+        size = (1.0 + (synth._hash_u32(torch.arange(B * tokens, dtype=torch.int64), 7) % 4).float()) if with_size else None
+        x = synth.uniform("tx", (B * tokens, D), 1.0, seed=tokens + 1)
+        # attention
+        got = ops.tome_attention(qkv.cuda(), size.cuda() if with_size else None, B, tokens, H, d, d ** -0.5).float().cpu()
+        q, k, v = qkv.float().reshape(B, tokens, 3, H, d).permute(2, 0, 3, 1, 4)
+        a = (q @ k.transpose(-1, -2)) * d ** -0.5
+        if with_size:
+            a = a + size.reshape(B, 1, 1, tokens).log()
+        ref = (a.softmax(-1) @ v).transpose(1, 2).reshape(B * tokens, H * d)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-3, rtol=2e-3)
+        # matching + merge
+        xo, so, index, metric = ops.tome_merge(qkv.cuda(), x.cuda(), size.cuda() if with_size else None, B, tokens, r, H, d)
+        torch.cuda.synchronize()
+        m_ref = k.mean(1)                                                    # (B, tokens, d)
+        np.testing.assert_allclose(metric.cpu().numpy(), m_ref.numpy(), atol=1e-6)
+        unm, src, dst = T.bipartite_match(metric.cpu(), r)                   # on the GPU's own metric: decisions must be identical
+        na = (tokens + 1) // 2
+        idx = index.cpu().long()
+        assert torch.equal(idx[:, 0, :na - r], unm) and torch.equal(idx[:, 1, :r], src) and torch.equal(idx[:, 2, :r], dst)
+        sz = size.reshape(B, tokens, 1) if with_size else torch.ones(B, tokens, 1)
+        x_ref, s_ref = T.merge_tokens(x.reshape(B, tokens, D), sz, unm, src, dst)
+        np.testing.assert_allclose(xo.cpu().reshape(B, tokens - r, D).numpy(), x_ref.numpy(), atol=2e-6, rtol=1e-6)
+        np.testing.assert_array_equal(so.cpu().reshape(B, tokens - r, 1).numpy(), s_ref.numpy())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_tome_forward_vs_oracle_and_reference_golden(golden_dir, dtype):
+    """The whole forward with token merging (HAMER_INFER(token_merge=True): apply_patch, r = (8, -1)) on the 6-block geometry:
+    192 -> 176 -> 164 -> 155 -> 149 -> 146 tokens.  Matching is a discrete decision on 16-bit keys, so the tight comparison is
+    with the oracle in the kernel's arithmetic (same keys, same decisions); the reference-module golden (fp32) is the second,
+    looser bound."""
+    from oracle import tome_ref as T
+    g = np.load(os.path.join(golden_dir, "hamer_tome.npz"))
+    cfg = synth.tome_tiny_config()
+    sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]))
+    mp = synth.mano_params(seed=0)
+    eng = HamerEngine(sd, mp, cfg, dtype=dtype, token_merge=True)
+    assert eng.tome_r == list(g["r_list"]) and eng.ctx_tokens == 146
+    img = synth.normalize_crops(synth.crops_u8(3, seed0=int(g["crop_seed0"])))
+    out = eng.forward(img.cuda(), want_tokens=True)
+    torch.cuda.synchronize()
+    tok = out["tokens"].float().cpu()[:3 * 146].reshape(3, 146, -1)
+    emu = "fp16" if dtype == torch.float16 else "bf16"
+    with torch.no_grad():
+        feats = T.vit_forward_tome(sd, img[:, :, :, 32:-32], cfg.vit, (8, -1), emu=emu)
+        pose, betas, cam = R.mano_head_forward(sd, R._q(feats, emu), cfg.dec, emu)
+    tol = 2e-2 if dtype == torch.float16 else 1e-1
+    d_tok = float((tok - feats).abs().max())
+    d_pose = float((out["pose6d"].cpu() - pose).abs().max())
+    g_pose = float(np.abs(out["pose6d"].cpu().numpy() - g["pose6d"]).max())
+    _report(f"tome_forward[{emu}]", tokens_vs_emu=d_tok, pose6d_vs_emu=d_pose, pose6d_vs_reference_fp32=g_pose)
+    assert d_tok < tol and d_pose < (1e-3 if dtype == torch.float16 else 4e-3)
+    assert g_pose < (2e-3 if dtype == torch.float16 else 1e-2)
+    assert torch.isfinite(out["pred_vertices"]).all()
+
+
+def test_tome_vith_schedule_runs_to_one_token():
+    """ViT-H with the reference's schedule: parse_r(32, (8, -1)) removes 241 of 192 tokens -- capped at half per block, the
+    sequence collapses to ONE token by block 19 (176, 161, ... 8, 4, 2, 1): the decoder then attends over a single context
+    token.  Whatever one thinks of that setting, it is what HAMER_INFER(token_merge=True) computes; check it runs, is finite,
+    deterministic, and that the result differs from the dense backbone."""
+    cfg = synth.HamerConfig()
+    sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
+    mp = synth.mano_params(seed=0)
+    eng = HamerEngine(sd, mp, cfg, token_merge=True)
+    assert eng.ctx_tokens == 1 and sum(eng.tome_r) == 241
+    img = synth.normalize_crops(synth.crops_u8(4, seed0=0)).cuda()
+    a = {k: v.clone() for k, v in eng.forward(img).items()}
+    b = eng.forward(img)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a[k], b[k]) for k in a) and torch.isfinite(a["pred_vertices"]).all()
+    dense = HamerEngine(sd, mp, cfg).forward(img)
+    assert float((dense["pose6d"] - a["pose6d"]).abs().max()) > 1e-3

@@ -402,3 +402,11 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_tome_schedule_parser_matches_oracle():
+    from hamer_yolo_amd.engine import parse_tome_r
+    from oracle import tome_ref as T
+    for n, r in ((32, (8, -1)), (6, (8, -1)), (12, 5), (4, [7, 2]), (24, (6, 0.5)), (8, (3, 1))):
+        assert parse_tome_r(n, r) == T.parse_r(n, r), (n, r)
+    assert sum(parse_tome_r(32, (8, -1))) == 241

@@ -84,3 +84,33 @@ def test_rootnet_head_bbox_and_k_match_reference(golden_dir):
     root = {"depth_layer.weight": torch.from_numpy(g["depth_w"]), "depth_layer.bias": torch.from_numpy(g["depth_b"])}
     d = RR.root_depth(root, torch.from_numpy(g["feats"]), torch.from_numpy(g["k_value"]))
     np.testing.assert_allclose(d.numpy(), g["depth"], rtol=1e-5, atol=1e-7)
+
+
+def test_tome_matches_reference_module(golden_dir):
+    """Token merging: oracle/tome_ref.py against hamer/hamer/models/backbones/selective_vit_adapter.py run on the same seeded
+    weights (apply_patch + r = (8, -1), as HAMER_INFER(token_merge=True) sets it, hamer.py:481-483)."""
+    from oracle import tome_ref as T
+    g = _load(golden_dir, "hamer_tome.npz")
+    assert T.parse_r(6, (8, -1)) == list(g["r_list"]) and T.parse_r(32, (8, -1)) == list(g["r_list_vith"])
+    assert T.parse_r(4, 5) == [5, 5, 5, 5] and T.parse_r(3, [7, 2]) == [7, 2, 0]
+    # the matching + size-weighted merge alone
+    metric = synth.uniform("golden.tome_metric", (2, 192, 80), 1.0, seed=9)
+    xs = synth.uniform("golden.tome_x", (2, 192, 24), 1.0, seed=9)
+    unm, src, dst = T.bipartite_match(metric, 16)
+    merged, msize = T.merge_tokens(xs, torch.ones(2, 192, 1), unm, src, dst)
+    np.testing.assert_allclose(merged.numpy(), g["merged"], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(msize.numpy(), g["merged_size"])
+    assert merged.shape == (2, 176, 24) and float(msize.sum()) == 2 * 192
+    # the whole backbone + head
+    cfg = synth.tome_tiny_config()
+    sd = synth.hamer_state_dict(cfg, seed=int(g["seed"]))
+    img = synth.normalize_crops(synth.crops_u8(3, seed0=int(g["crop_seed0"])))
+    trace = {}
+    with torch.no_grad():
+        feats = T.vit_forward_tome(sd, img[:, :, :, 32:-32], cfg.vit, (8, -1), trace=trace)
+        pose, betas, cam = R.mano_head_forward(sd, feats, cfg.dec)
+    assert trace["tokens"] == [176, 164, 155, 149, 146, 146] and feats.shape == (3, 146, 320)
+    np.testing.assert_allclose(feats.numpy(), g["tokens"], atol=3e-5, rtol=0)
+    np.testing.assert_allclose(pose.numpy(), g["pose6d"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(betas.numpy(), g["betas"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(cam.numpy(), g["cam"], atol=2e-5, rtol=0)

@@ -61,6 +61,13 @@ def load_reference_modules():
     return vit, pt, geo
 
 
+def load_reference_tome():
+    """selective_vit_adapter.py (ToMe): ``from .vit import Attention, Block, ViT`` resolves to the module loaded above."""
+    base = os.path.join(REF, "hamer", "hamer")
+    return _load("refhamer.models.backbones.selective_vit_adapter", os.path.join(base, "models/backbones/selective_vit_adapter.py"),
+                 "refhamer.models.backbones")
+
+
 def load_manopth():
     base = os.path.join(REF, "rootnet/KeypointFusion/manopth")
     for pkg, path in (("refmano", []), ("refmano.manopth", [os.path.join(base, "manopth")]),
@@ -190,6 +197,33 @@ def main():
         err = float((v_ref - v_or).abs().max())
         print(f"real MANO_RIGHT.pkl: oracle LBS vs manopth max |dv| = {err:.2e} m")
         assert err < 5e-6
+
+    # ---- token merging (HAMER_INFER(token_merge=True), hamer.py:481-483: apply_patch + r = (8, -1)) on a 6-block geometry
+    tome = load_reference_tome()
+    cfg = synth.tome_tiny_config()
+    sd = synth.hamer_state_dict(cfg, seed=7)
+    img = synth.normalize_crops(synth.crops_u8(3, seed0=70))
+    with torch.no_grad():
+        vit = build_ref_vit(vitmod, cfg, sd)
+        tome.apply_patch(vit)                      # trace_source=False, prop_attn=True (the defaults HAMER_INFER uses)
+        vit.r = (8, -1)
+        feats = vit(img[:, :, :, 32:-32])
+        dec = build_ref_decoder(ptmod, cfg, sd)
+        tok = dec(torch.zeros(3, 1, 1), context=feats).squeeze(1)
+        F = torch.nn.functional
+        pose = F.linear(tok, sd["mano_head.decpose.weight"], sd["mano_head.decpose.bias"]) + sd["mano_head.init_hand_pose"]
+        betas = F.linear(tok, sd["mano_head.decshape.weight"], sd["mano_head.decshape.bias"]) + sd["mano_head.init_betas"]
+        cam = F.linear(tok, sd["mano_head.deccam.weight"], sd["mano_head.deccam.bias"]) + sd["mano_head.init_cam"]
+        # the matching of the first block alone, on the metric the reference computes there
+        metric = synth.uniform("golden.tome_metric", (2, 192, 80), 1.0, seed=9)
+        merge, _ = tome.bipartite_soft_matching(metric, 16)
+        xs = synth.uniform("golden.tome_x", (2, 192, 24), 1.0, seed=9)
+        merged, msize = tome.merge_wavg(merge, xs)
+    np.savez_compressed(os.path.join(OUT, "hamer_tome.npz"), seed=7, crop_seed0=70, r=np.array([8, -1]),
+                        r_list=np.array(tome.parse_r(cfg.vit.depth, (8, -1))), r_list_vith=np.array(tome.parse_r(32, (8, -1))),
+                        tokens=feats.numpy(), token_out=tok.numpy(), pose6d=pose.numpy(), betas=betas.numpy(), cam=cam.numpy(),
+                        merged=merged.numpy(), merged_size=msize.numpy())
+    print("tome: tokens", feats.shape)
 
     if args.full:
         cfg = synth.HamerConfig()
