@@ -814,6 +814,115 @@ int launch_rs(const KArgs& g, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (variant 28): 256x160 tile with BOTH operands two K-steps ahead.  The 256x256 K loop runs at the latency of
+// its copies: W is requested one step before it is needed because a third 32 KB W slot does not fit beside three X slots
+// (160 KB).  A 256x160 tile (waves 4x2, each 64x80 = 4x5 MFMA tiles) fits three slots of each operand (96 + 60 KB), so
+// every copy has two full steps to land; it pays 27 % more operand bytes per flop.  Uses the generic epilogue.
+template <class T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_d2_kernel(const KArgs g) {
+  constexpr int WN = 2, MI = 4, NI = 5, NW = 8, BM = 256, BN = 160, ROWB = 128;
+  constexpr int XT = BM * ROWB, WT = BN * ROWB;                         // 32 KB, 20 KB
+  constexpr int XRING = 0, WRING = 3 * XT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using vec8 = typename T::vec8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wr = wave / WN, wc = wave % WN;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+  const int srow = lane >> 3, swz = (lane & 7) ^ (srow & 7);
+  const int nwp = wave < 4 ? 3 : 2;                                     // W pieces of this wave: 20 pieces over 8 waves
+  unsigned xoff[4], woff[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int gm = m0 + wave * 32 + i * 8 + srow;
+    gm = gm < g.M ? gm : g.M - 1;
+    xoff[i] = (unsigned)gm * (unsigned)(g.ldx * 2) + swz * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int gn = n0 + (wave + 8 * i) * 8 + srow;                            // piece p = wave + 8 i
+    gn = gn < g.N ? gn : g.N - 1;
+    woff[i] = (unsigned)gn * (unsigned)(g.ldw * 2) + swz * 16;
+  }
+  float bias_reg = 0.f;
+  if (g.bias) bias_reg = g.bias[min(n0 + (tid % BN), g.N - 1)];         // the oldest vector-memory operation: every wait below covers it
+  auto dma = [&](int slot, int kt) {
+    const char* xb = X + (size_t)kt * ROWB;
+    const char* wb = W + (size_t)kt * ROWB;
+    char* lx = smem + XRING + slot * XT + wave * 4 * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16_hidden_s(xb, xoff[i], lx + i * 1024);
+    char* lw = smem + WRING + slot * WT;
+    glds16_hidden_s(wb, woff[0], lw + wave * 1024);
+    glds16_hidden_s(wb, woff[1], lw + (wave + 8) * 1024);
+    if (wave < 4) glds16_hidden_s(wb, woff[2], lw + (wave + 16) * 1024);
+  };
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fsw = lane & 7, fch = lane >> 4;
+  auto substep = [&](int slot, int ks) {
+    const char* lx = smem + XRING + slot * XT;
+    const char* lw = smem + WRING + slot * WT;
+    const int coff = ((ks * 4 + fch) ^ fsw) * 16;
+    vec8 wf[NI], xf[MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto wait_step = [&](bool more) {                                     // all but the next step's copies (4 X + nwp W) have landed
+    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nwp == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  };
+  const int nk = g.K / 64;
+  dma(0, 0);
+  if (nk > 1) dma(1, 1);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_step(kt + 1 < nk);
+    __builtin_amdgcn_s_barrier();                      // step kt complete in LDS; everyone is done reading step kt-1's slot
+    substep(slot, 0);
+    if (kt + 2 < nk) dma(slot == 0 ? 2 : slot - 1, kt + 2);            // (kt + 2) % 3 = the slot step kt-1 read
+    substep(slot, 1);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  __builtin_amdgcn_s_barrier();
+  constexpr int EPI_BYTES = NW * epi_stage_bytes(MI, NI);
+  float2* rowstat = (float2*)(smem + EPI_BYTES);       // unused by these epilogues
+  float* colvec = (float*)(rowstat + BM);
+  if (tid < BN) colvec[tid] = bias_reg;
+  __builtin_amdgcn_s_barrier();
+  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI),
+                           rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI, 0);
+}
+
+template <class T, int EPI>
+int launch_d2(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 3 * 256 * 128 + 3 * 160 * 128;                    // 159,744 B
+  auto kern = gemm_d2_kernel<T, EPI>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 159) / 160);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, g);
+  return hm_check_launch("hm_gemm");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Persistent form of gemm_x3_kernel for the 16-bit store epilogues (qkv, fc1, to_kv: 3-5 tiles per CU at B = 64).
 // Launched tile by tile, every tile pays its own start-up in series with everything else on its CU -- address set-up,
 // the first HBM/L2 round trip of its operands (nothing to overlap it with: one workgroup per CU), the wait for its
@@ -1065,6 +1174,11 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
     case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
     case 25: return launch_cfg<T, EPI, 4, 2, 4, 10, 2, false, 64, 2>(g, s, "hm_gemm"); // 256x320, waves 4x2 (64x160 each), 2 stages (144 KB)
+    case 28:                                                                           // EXPERIMENT: 256x160, both operands two steps ahead
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
+        if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_d2<T, EPI>(g, s);
+      }
+      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
     case 26:                                                                           // persistent 256x256 (gemm_px_kernel), else as 24
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
         if (px_ok(g)) return launch_px<T, EPI>(g, s);
@@ -1099,7 +1213,7 @@ bool variant_ok(int v) {
 #ifdef HM_ABLATIONS
   if (v == 14 || v == 15 || v == 18 || v == 20) return true;
 #endif
-  return (v >= 0 && v <= 11) || (v >= 21 && v <= 26);
+  return (v >= 0 && v <= 11) || (v >= 21 && v <= 26) || v == 28;
 }
 
 int pick_variant(const KArgs& g) {
@@ -1176,7 +1290,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..26");
+  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..26, 28");
   g_variant = v;
   return HM_OK;
 }

@@ -124,22 +124,25 @@ def test_gemm_persistent_kernel_exact(dt):
         lib.hm_gemm_set_variant(-1)
 
 
+@pytest.mark.parametrize("variant", [25, 28])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_gemm_256x320_tile_exact(dt):
-    """Variant 25 (256x320 tile, the fc1 choice at B = 64) on exact-integer data, ragged and whole shapes, every epilogue
-    family it can be given: 16-bit store, fp32 out, fp32 residual."""
+def test_gemm_256x320_tile_exact(dt, variant):
+    """Variant 25 (256x320 tile) and variant 28 (256x160 tile, both operands two K-steps ahead in three-slot rings, hand-counted
+    vmcnt with a wave-dependent copy count) on exact-integer data, ragged and whole shapes, 1 / 2 / 3 / many K-steps, every
+    epilogue family they can be given: 16-bit store, fp32 out, fp32 residual; repeated launches as a race screen."""
     lib = L.load()
     try:
-        L.check(lib.hm_gemm_set_variant(25))
-        for (M, N, K) in ((300, 260, 64), (513, 388, 128), (1000, 1284, 448), (768, 5120, 1280), (2304, 640, 192)):
+        L.check(lib.hm_gemm_set_variant(variant))
+        for (M, N, K) in ((300, 260, 64), (513, 388, 128), (1000, 1284, 448), (768, 5120, 1280), (2304, 640, 192), (4096, 3840, 192)):
             x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
             w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
             bias = (torch.arange(N) % 9 - 4).float()
             resid = ((torch.arange(M * N).reshape(M, N) * 3) % 11 - 5).float()
             xd, wd, bd, rd = x.to(DEV, dt), w.to(DEV, dt), bias.to(DEV), resid.to(DEV)
-            ref = x @ w.t() + bias
+            ref = (xd.float() @ wd.float().t()).cpu() + bias
             assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_F32).cpu(), ref), (M, N, K)
-            assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd).cpu(), ref + resid), (M, N, K)
+            for _ in range(3):
+                assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd).cpu(), ref + resid), (M, N, K)
             if N % 8 == 0:
                 assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_STORE).float().cpu(), ref.to(dt).float()), (M, N, K)
     finally:
