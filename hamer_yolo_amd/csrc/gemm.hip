@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int BK_DEFAULT = 64;
+int g_px_grid = -2;    // workgroups of gemm_px_kernel: -2 read HM_PX_GRID on first use, -1 default
 
 struct KArgs {                                    // kernel-side view of either entry point
   const void* X; const void* W; void* C; const float* bias; const float* resid;
@@ -1108,7 +1109,15 @@ int launch_px(const KArgs& g, hipStream_t s) {
   const int tiles = (g.M >> 8) * (g.N >> 8);
   int cus = hm_device_cu_count();
   if (cus <= 0) cus = 256;
-  const int grid = (tiles < cus ? tiles : cus) & ~7;               // one workgroup per CU, a multiple of the 8 XCDs
+  if (g_px_grid == -2) {
+    const char* e = getenv("HM_PX_GRID");                          // tuning runs: workgroups of the persistent GEMM (default: one per CU)
+    g_px_grid = e ? atoi(e) : -1;
+  }
+  // (Leaving 16 of the 256 CUs to the other stream's LayerNorm / attention workgroups -- 240 workgroups: the same number of
+  // tile-times for 720 / 960 tiles -- was measured neutral with two batches in flight: 3656-3673 hands/s at 224 / 240 / 248 / 256.)
+  int want = g_px_grid > 0 ? g_px_grid : cus;
+  if (want > cus) want = cus;
+  const int grid = (tiles < want ? tiles : want) & ~7;             // a multiple of the 8 XCDs
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);
   return hm_check_launch("hm_gemm");
 }
