@@ -353,10 +353,32 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
         if cur:
             yield cur
 
-    def enqueue(chunk, stream):
+    pinned = {}                       # (stream slot, frame shape) -> page-locked staging buffer of one chunk of frames
+
+    def upload(chunk, slot, pool):
+        """The chunk's frames -> device through a page-locked staging buffer: the copies into it run on the decode pool's
+        threads, the transfer itself is one asynchronous H2D on the chunk's stream (a pageable `.to(device)` per frame
+        costs the host 1-1.5 ms each, in series with everything else it has to do)."""
+        shape = chunk[0][1].shape
+        key = (slot, shape)
+        if key not in pinned:
+            pinned[key] = torch.empty((frames_per_step,) + tuple(shape), dtype=torch.uint8, pin_memory=True)
+        buf = pinned[key]
+        views = buf.numpy()
+
+        def put(i):
+            np.copyto(views[i], chunk[i][1])
+        list(pool.map(put, range(len(chunk))))
+        d = buf[:len(chunk)].to(dev, non_blocking=True)
+        return [d[i] for i in range(len(chunk))]
+
+    def enqueue(chunk, stream, slot=0, pool=None):
         """Detector pass (+ its one sync), crops, HaMeR forward and camera step of one chunk, all on `stream`."""
         with torch.cuda.stream(stream):
-            frames = [torch.from_numpy(np.ascontiguousarray(im)).to(dev) for _, im in chunk]
+            if pool is not None and len(chunk) <= frames_per_step:
+                frames = upload(chunk, slot, pool)
+            else:
+                frames = [torch.from_numpy(np.ascontiguousarray(im)).to(dev) for _, im in chunk]
             if hasattr(detector, "detect_frames"):
                 _, dets_lists = detector.detect_frames(frames)
             else:                                              # any object with the reference's detect(image) works too
@@ -383,7 +405,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             sel = np.nonzero(fidx == j)[0]
             yield pth, dets, {k: v[sel] for k, v in res.items()}
 
-    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+    with ThreadPoolExecutor(max_workers=nthreads) as pool, ThreadPoolExecutor(max_workers=min(8, nthreads)) as copy_pool:
         block = frames_per_step * 4                         # decode ahead in blocks; the next block decodes while this one runs
         starts = list(range(0, len(image_paths), block))
         decode = lambda paths: [pool.submit(_imread_bgr, p) for p in paths]
@@ -396,7 +418,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             images = [f.result() for f in futs]
             for chunk in chunks_of(paths, images):
                 try:
-                    job = enqueue(chunk, streams[k % len(streams)])
+                    job = enqueue(chunk, streams[k % len(streams)], k % len(streams), copy_pool)   # (own pool: not behind the queued decodes)
                 except Exception as e:                    # isolate the bad file: redo this chunk image by image
                     print(f"Error processing chunk starting at {chunk[0][0]}: {e}")
                     job = None
