@@ -34,8 +34,9 @@ def setv(v):
 
 
 for (name, K, N, epi) in shapes:
-    x = torch.randn(M, K, device=dev).to(DT)
-    w = (torch.randn(N, K, device=dev) * 0.02).to(DT)
+    PAD = int(os.environ.get("PAD", 0))            # extra elements per operand row (row pitch = K + PAD): L2 channel spread experiment
+    x = torch.randn(M, K + PAD, device=dev).to(DT)[:, :K]
+    w = (torch.randn(N, K + PAD, device=dev) * 0.02).to(DT)[:, :K]
     b = torch.randn(N, device=dev)
     f32 = epi == L.HM_EPI_RESID_F32
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else DT)
