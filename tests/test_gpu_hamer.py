@@ -273,3 +273,27 @@ def test_tome_vith_schedule_runs_to_one_token():
     assert all(torch.equal(a[k], b[k]) for k in a) and torch.isfinite(a["pred_vertices"]).all()
     dense = HamerEngine(sd, mp, cfg).forward(img)
     assert float((dense["pose6d"] - a["pose6d"]).abs().max()) > 1e-3
+
+
+def test_persistent_gemm_is_bit_identical_to_one_tile_kernels_at_batch64():
+    """gemm_px_kernel (the default for qkv / fc1 / to_kv at B = 64: 720 / 960 / 1152 tiles on 256 persistent workgroups, LDS-DMA
+    pipeline across tile boundaries, hand-counted vmcnt) rounds exactly as the one-tile kernels do, so a whole B = 64 forward
+    must come out bit for bit the same with it (default) and without it (variant 24) -- on random data, three times over: any
+    tile that ever read a stale or half-landed LDS slot would show up here."""
+    from hamer_yolo_amd import lib as L
+    cfg = synth.HamerConfig()
+    sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
+    eng = HamerEngine(sd, synth.mano_params(seed=0), cfg)
+    img = synth.normalize_crops(synth.crops_u8(64, seed0=500)).cuda()
+    lib = L.load()
+    try:
+        L.check(lib.hm_gemm_set_variant(24))
+        ref = {k: v.clone() for k, v in eng.forward(img, want_tokens=True).items()}
+        L.check(lib.hm_gemm_set_variant(-1))
+        for _ in range(3):
+            out = eng.forward(img, want_tokens=True)
+            torch.cuda.synchronize()
+            for k in ref:
+                assert torch.equal(out[k], ref[k]), k
+    finally:
+        lib.hm_gemm_set_variant(-1)
