@@ -357,7 +357,7 @@ def main():
         if args.dtype == "fp8":      # dominant kernel = gemm_fp8_kernel: price its launches against the fp8 peak
             f8 = [(M_, N_, K_, ms_) for (kd, e_, M_, N_, K_, ms_) in prof.records if kd == "gemm" and e_ >= 16]
             achieved = sum(2.0 * a * b * c for a, b, c, _ in f8) / (sum(t for *_, t in f8) * 1e-3) / 1e12
-            kernel_name, peak, traffic = "gemm_fp8_kernel (store / gelu_mx8 / resid_f32)", PEAK_FP8_TFLOPS, None
+            kernel_name, peak, traffic = "gemm_fp8p_kernel (store / gelu_mx8) + gemm_fp8_kernel (resid_f32)", PEAK_FP8_TFLOPS, None
         res["roofline"] = {
             "kernel": kernel_name, "bound": "mfma", "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,

@@ -694,6 +694,13 @@ __device__ __forceinline__ void glds16_hidden_s(const char* base, unsigned off, 
                : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
 }
 
+__device__ __forceinline__ void glds4_hidden_s(const char* base, unsigned off, void* lds_wave_base) {   // 4 bytes per lane
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+}
+
 template <class T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const KArgs g) {
   constexpr int WM = 4, WN = 2, MI = 4, NI = 8, NW = 8, BM = 256, BN = 256, BK = 64, ROWB = 128;
@@ -1128,6 +1135,215 @@ bool px_ok(const KArgs& g) {
          256ull * g.ldx * 2 < (1ull << 32) && 256ull * g.ldw * 2 < (1ull << 32) && (((uintptr_t)g.C) & 15) == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of gemm_fp8_kernel (the gemm_px_kernel idea on the fp8 MFMA) for the qkv (bf16 out) and fc1 (GELU ->
+// MXFP8 out) GEMMs of BASELINE configs[4].  An fp8 K-step carries twice the flops of a 16-bit one, so a K = 1280 tile is
+// only 10 steps (~15 us) and the per-tile start-up / drain of the one-tile kernel is ~40 % of its time at B = 256.
+// Two-stage ring as in gemm_fp8_kernel; at a tile's LAST step the free stage receives the NEXT tile's first K-step, which
+// lands under that step's MFMAs and the epilogue.  The epilogue stages through the stage the last step read (4 KB per
+// wave + 1 KB of per-column bias / weight scales that travelled in four registers), issues no loads, and a fixed number
+// of stores per wave: 16 (bf16 out) or 32 (MXFP8 out: 16 data + 16 block-scale stores), which the next tile's first wait
+// counts around.  Whole tiles only (M, N multiples of 256; K >= 256).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_fp8p_kernel(const KArgs g) {
+  static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU_MX8, "qkv / fc1 epilogues");
+  constexpr int WN = 2, MI = 4, NI = 8, BM = 256, BKB = 128;
+  constexpr int TILE_BYTES = 256 * BKB, SCALE_BYTES = 4 * BM, STAGE_BYTES = 2 * TILE_BYTES + SCALE_BYTES;
+  constexpr int NSTORE = EPI == HM_EPI_STORE ? 16 : 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = g.N >> 8, tiles_m = g.M >> 8, tiles = tiles_m * tiles_n;
+  const int G = gridDim.x, xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per = G >> 3;
+  const int tq = tiles >> 3, tr = tiles & 7;
+  const int run_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_len = tq + (xcd < tr ? 1 : 0);
+  const int my = li < run_len ? (run_len - li + per - 1) / per : 0;
+  if (my == 0) return;
+  const int nk = g.K / BKB, S = my * nk;
+  const int wr = wave / WN, wc = wave % WN;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+  const int srow = lane >> 3, chunk = (lane & 7) ^ (srow & 7);
+  unsigned xoff[4], woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xoff[i] = (unsigned)(wave * 32 + i * 8 + srow) * (unsigned)g.ldx + chunk * 16;
+    woff[i] = (unsigned)(wave * 32 + i * 8 + srow) * (unsigned)g.ldw + chunk * 16;
+  }
+  const unsigned soff = (unsigned)(lane >> 4) * (unsigned)g.M + 16 * (lane & 15);      // block scales: 16 rows of one k-block per lane
+  auto origin = [&](int ti, int& m0, int& n0) {
+    int tm, tn;
+    tile_coords(run_lo + li + ti * per, tiles_m, tiles_n, g.group_m, tm, tn);
+    m0 = tm << 8; n0 = tn << 8;
+  };
+  int lti = 0, lkt = 0, m0, n0;                         // load cursor: one K-step ahead of the MFMAs
+  origin(0, m0, n0);
+  const char* xbase = X + (size_t)m0 * g.ldx;
+  const char* wbase = W + (size_t)n0 * g.ldw;
+  const char* sbase = (const char*)g.xs + m0;
+  auto load_step = [&](int buf) {                       // the cursor's K-step -> stage `buf`, then advance the cursor
+    char* st = smem + buf * STAGE_BYTES;
+    const char* xb = xbase + (size_t)lkt * BKB;
+    const char* wb = wbase + (size_t)lkt * BKB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16_hidden_s(xb, xoff[i], st + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16_hidden_s(wb, woff[i], st + TILE_BYTES + (wave * 4 + i) * 1024);
+    if (wave == 0) glds16_hidden_s(sbase + (size_t)lkt * 4 * g.M, soff, st + 2 * TILE_BYTES);
+    if (++lkt == nk) {
+      lkt = 0;
+      if (++lti < my) {
+        int a, b;
+        origin(lti, a, b);
+        xbase = X + (size_t)a * g.ldx; wbase = W + (size_t)b * g.ldw; sbase = (const char*)g.xs + a;
+      }
+    }
+  };
+
+  f32x4_t acc[NI][MI];
+  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+  const int c_lo = ((fg ^ fsw) * 16), c_hi = (((4 + fg) ^ fsw) * 16);
+  auto kstep = [&](int buf) {
+    const char* lx = smem + buf * STAGE_BYTES;
+    const char* lw = lx + TILE_BYTES;
+    const unsigned char* ls = (const unsigned char*)(lx + 2 * TILE_BYTES) + fg * BM + wr * 64 + frow;
+    v8i_t xf[MI];
+    int xsc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const char* r = lx + (wr * 64 + i * 16 + frow) * BKB;
+      const v4i_t lo = *(const v4i_t*)(r + c_lo), hi = *(const v4i_t*)(r + c_hi);
+      xf[i] = v8i_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      xsc[i] = ls[i * 16];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      v8i_t wf[NI / 2];
+#pragma unroll
+      for (int i = 0; i < NI / 2; ++i) {
+        const char* r = lw + (wc * 128 + (h * 4 + i) * 16 + frow) * BKB;
+        const v4i_t lo = *(const v4i_t*)(r + c_lo), hi = *(const v4i_t*)(r + c_hi);
+        wf[i] = v8i_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NI / 2; ++i)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[h * 4 + i][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], xf[mi], acc[h * 4 + i][mi], 0, 0, 0, 127, 0, xsc[mi]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  float* cb = (float*)(smem + 2 * STAGE_BYTES) + wave * 256;          // [128 bias | 128 weight scales], wave-private
+  load_step(0);
+  int gs = 0, rd = 0;
+  for (int ti = 0; ti < my; ++ti) {
+    if (ti > 0) origin(ti, m0, n0);
+    // bias and weight scale of this wave's 128 columns -> the wave's own 1 KB of LDS by dword LDS-DMA: no register, no
+    // compiler-placed wait (a plain load here makes hipcc drain vmcnt to 0 wherever the value is first touched)
+    {
+      const char* bsrc = (const char*)(g.bias + n0 + wc * 128);
+      const char* wsrc = (const char*)(g.wscale + n0 + wc * 128);
+      glds4_hidden_s(bsrc, lane * 4, cb);
+      glds4_hidden_s(bsrc + 256, lane * 4, cb + 64);
+      glds4_hidden_s(wsrc, lane * 4, cb + 128);
+      glds4_hidden_s(wsrc + 256, lane * 4, cb + 192);
+    }
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt, ++gs) {
+      // the loads of this step were issued one step ago -- before the previous tile's epilogue stores when kt == 0
+      if (gs > 0 && kt == 0) {
+        if constexpr (NSTORE == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");     // stores + the 4 bias / scale copies above
+        else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (gs + 1 < S) load_step(rd ^ 1);
+      kstep(rd);
+      rd ^= 1;
+    }
+    __builtin_amdgcn_s_barrier();                      // the last step's stage (rd ^ 1 now) is free: epilogue staging
+    char* stg = smem + (rd ^ 1) * STAGE_BYTES;
+    char* wl = stg + wave * 4096;
+    const int arow = lane & 15, apiece = lane >> 4, row0 = lane >> 2, j = lane & 3;
+    const int mb = m0 + wr * 64, nb = n0 + wc * 128;
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+      const f32x4_t b0 = *(const f32x4_t*)(cb + cg * 32 + 8 * j), b1 = *(const f32x4_t*)(cb + cg * 32 + 8 * j + 4);
+      const f32x4_t w0 = *(const f32x4_t*)(cb + 128 + cg * 32 + 4 * apiece), w1 = *(const f32x4_t*)(cb + 128 + cg * 32 + 16 + 4 * apiece);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            const int row = mm * 16 + arow;
+            *(f32x4_t*)(wl + row * 128 + (((nl * 4 + apiece) ^ (row & 7)) << 4)) = acc[cg * 2 + nl][half * 2 + mm] * (nl ? w1 : w0);
+          }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 16 + row0, sw = row & 7, m = mb + half * 32 + row, n = nb + cg * 32 + 8 * j;
+          f32x4_t v0 = *(const f32x4_t*)(wl + row * 128 + (((2 * j) ^ sw) << 4));
+          f32x4_t v1 = *(const f32x4_t*)(wl + row * 128 + (((2 * j + 1) ^ sw) << 4));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v0[q] = __fadd_rn(v0[q], b0[q]); v1[q] = __fadd_rn(v1[q], b1[q]); }
+          if constexpr (EPI == HM_EPI_GELU_MX8) {
+            float amax = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x2_t gq = gelu_fast2(f32x2_t{v0[q], v1[q]});
+              v0[q] = gq[0]; v1[q] = gq[1];
+              amax = fmaxf(amax, fmaxf(fabsf(v0[q]), fabsf(v1[q])));
+            }
+            const unsigned sb = mx8_scale_byte(quad_max(amax));        // the 4 lanes of a row hold one 32-column block
+            const float inv = mx8_inv_scale(sb);
+            int2 o8;
+            o8.x = mx8_pack4(v0[0] * inv, v0[1] * inv, v0[2] * inv, v0[3] * inv);
+            o8.y = mx8_pack4(v1[0] * inv, v1[1] * inv, v1[2] * inv, v1[3] * inv);
+            *(int2*)((char*)g.C + (size_t)m * g.ldc + n) = o8;
+            // one scale byte per (row, block): every lane of the quad issues the store, all to the same byte with the same
+            // value -- an unconditional instruction, so the store count per wave is a constant
+            g.out_scales[(size_t)(n >> 5) * g.M + m] = (unsigned char)sb;
+          } else {
+            bf16x8_t o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o[q] = (__bf16)v0[q]; o[4 + q] = (__bf16)v1[q]; }
+            *(bf16x8_t*)((__bf16*)g.C + (size_t)m * g.ldc + n) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_fp8p(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 2 * (2 * 256 * 128 + 4 * 256) + 8 * 1024;
+  auto kern = gemm_fp8p_kernel<EPI>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_gemm_fp8: cannot raise the dynamic LDS limit")) return rc;
+  const int tiles = (g.M >> 8) * (g.N >> 8);
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  if (const char* e = getenv("HM_FP8P_GRID")) {         // tests: few workgroups, many tiles each
+    const int v = atoi(e);
+    if (v >= 8) cus = v;
+  }
+  const int grid = (tiles < cus ? tiles : cus) & ~7;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);
+  return hm_check_launch("hm_gemm_fp8");
+}
+
+bool fp8p_ok(const KArgs& g) {
+  return g.bias != nullptr && g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 256 && (g.M >> 8) * (g.N >> 8) >= 8 && 256ull * g.ldx < (1ull << 32) &&
+         256ull * g.ldw < (1ull << 32) && 4ull * g.M < (1ull << 32) && getenv("HM_FP8_ONE_TILE") == nullptr;
+}
+
 // partial (sum, sum of squares) per 64 columns [P][M][2] -> (mean, rstd) per row [M][2]
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ fin, int M, int P,
                                                           float invD, float eps) {
@@ -1369,9 +1585,12 @@ extern "C" int hm_gemm_fp8(const hm_gemm_fp8_args* a, void* stream_) {
   switch (g.epilogue) {
     case HM_EPI_STORE:
       if (g.out_dtype != HM_DTYPE_BF16) return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: HM_EPI_STORE writes bf16 (out_dtype HM_DTYPE_BF16)");
+      if (fp8p_ok(k) && (g.ldc & 7) == 0) return launch_fp8p<HM_EPI_STORE>(k, stream);
       return launch_fp8<HM_EPI_STORE>(k, stream);
     case HM_EPI_RESID_F32: return launch_fp8<HM_EPI_RESID_F32>(k, stream);
-    case HM_EPI_GELU_MX8: return launch_fp8<HM_EPI_GELU_MX8>(k, stream);
+    case HM_EPI_GELU_MX8:
+      if (fp8p_ok(k) && (g.ldc & 7) == 0) return launch_fp8p<HM_EPI_GELU_MX8>(k, stream);
+      return launch_fp8<HM_EPI_GELU_MX8>(k, stream);
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: epilogue must be STORE, RESID_F32 or GELU_MX8");
   }
 }

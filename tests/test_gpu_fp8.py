@@ -91,6 +91,28 @@ def test_layernorm_mx8(D):
     assert ((d_k - y).abs() <= blockmax * 2.0 ** -4 + 1e-6).float().mean().item() > 0.999
 
 
+@pytest.mark.parametrize("grid", [None, "8", "40"])
+def test_gemm_fp8_persistent_kernel_is_bit_identical_to_one_tile_kernel(grid, monkeypatch):
+    """qkv / fc1 shapes of whole 256 x 256 tiles run in the persistent kernel (several tiles per workgroup, the next tile's
+    first K-step in flight under the epilogue, hand-counted waits).  Same MFMA order, same epilogue arithmetic: the bytes
+    must equal the one-tile kernel's, for one tile per workgroup (default grid) and for many (HM_FP8P_GRID)."""
+    M, N, K = 2304, 3840, 1280                       # 9 x 15 tiles
+    x8, xs, w8, ws, _ = _operands(M, N, K, seed=11)
+    bias = _u("fb", (N,), 0.5, seed=5)
+    a = (x8.to(DEV), xs.to(DEV), w8.to(DEV), ws.to(DEV), bias.to(DEV))
+    monkeypatch.setenv("HM_FP8_ONE_TILE", "1")
+    ref_store = ops.gemm_fp8(*a, L.HM_EPI_STORE)
+    ref8, refs = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
+    monkeypatch.delenv("HM_FP8_ONE_TILE")
+    if grid:
+        monkeypatch.setenv("HM_FP8P_GRID", grid)
+    for _ in range(2):
+        out = ops.gemm_fp8(*a, L.HM_EPI_STORE)
+        o8, os_ = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
+        assert torch.equal(out.view(torch.int16), ref_store.view(torch.int16))
+        assert torch.equal(o8, ref8) and torch.equal(os_, refs)
+
+
 def test_gemm_fp8_rejects_bad_arguments():
     x8 = torch.zeros(16, 128, device=DEV, dtype=torch.uint8)
     xs = torch.zeros(4, 16, device=DEV, dtype=torch.uint8)
