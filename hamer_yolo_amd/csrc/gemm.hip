@@ -1044,7 +1044,13 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     // this wave's 128 bias values, two per lane: requested now, first touched at the top of the tile's last K-step (so the
     // compiler's wait for them sits where nothing but already-needed copies is outstanding), moved to LDS after the loop
     float bias_lo = 0.f, bias_hi = 0.f;
-    if (g.bias) { bias_lo = g.bias[n0 + wc * 128 + lane]; bias_hi = g.bias[n0 + wc * 128 + 64 + lane]; }
+    if (g.bias) {
+      // issued from asm so that hipcc does not track them: a tracked load makes it drain vmcnt to 0 where the value is
+      // first touched (the epilogue's top, with the next tile's copies in flight).  The counted waits of steps >= 1
+      // cover them; nothing reads the two registers before the epilogue (checked in the ISA: tools/isa_vm_trace.py).
+      asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:256"
+                   : "=&v"(bias_lo), "=&v"(bias_hi) : "v"(lane * 4), "s"(g.bias + n0 + wc * 128) : "memory");
+    }
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
@@ -1052,12 +1058,14 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     int xs_last = 0, ws_last = 0;
     for (int kt = 0; kt < nk; ++kt, ++gs) {
       if (gs > 0) {
-        if (kt == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");          // 16 epilogue stores + X(gs+1) may stay in flight
+        if (kt == 0) {                                 // 16 epilogue stores + X(gs+1) (+ the 2 bias loads) may stay in flight
+          if (g.bias) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        }
         else if (gs + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // X(gs+1)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();                    // step gs complete in LDS; everyone is done with step gs-1's slots (and epilogue)
-      if (kt == nk - 1) asm volatile("" :: "v"(bias_lo), "v"(bias_hi));
       const int ws = gs & 1, xs2 = xs == 0 ? 2 : xs - 1;
       substep(xs, ws, 0);
       if (gs + 1 < S) { dma_w(ws ^ 1, wbase + (size_t)wkt * ROWB); next_w(); }   // W first, then X: the counted waits rely on this order
