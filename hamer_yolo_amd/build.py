@@ -23,17 +23,21 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = True, ablations: bool = False) -> str:
+    """ablations=True: the timing-ablation build (-DHM_ABLATIONS: GEMM variants that skip work and give WRONG results) into
+    a separate libhamer_hip_abl.so that only tools/bench_gemm_ab.py loads; the product library never contains them."""
+    lib = LIB.replace(".so", "_abl.so") if ablations else LIB
+    if not ablations and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build_abl" if ablations else "build")
+    os.makedirs(bdir, exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \
+              (["-DHM_ABLATIONS"] if ablations else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     failed = False
@@ -46,11 +50,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(f"[build] {src}:\n{outp}\n")
     if failed:
         raise RuntimeError("hipcc failed building libhamer_hip.so")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     if verbose:
-        sys.stderr.write(f"[build] wrote {LIB}\n")
-    return LIB
+        sys.stderr.write(f"[build] wrote {lib}\n")
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, ablations="--ablations" in sys.argv)

@@ -16,6 +16,7 @@
 // so a lane's 4 accumulator registers are 4 consecutive output columns of one row: bias / residual /
 // outputs move as 8- or 16-byte vectors.  Tiles are walked in an XCD-aware order.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "hamer_hip_internal.h"
 
@@ -1144,6 +1145,149 @@ bool px_ok(const KArgs& g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Variant 29: the 256x256x64 tile on FOUR waves (one per SIMD), each owning a 128x128 quadrant = 8x8 MFMA tiles.
+// Per K-step and CU that is 64 ds_read_b128 instead of the 96 of the 8-wave kernels (2/3 of the LDS traffic per flop) and
+// a wave may use the whole 512-entry register file: 256 accumulator registers, and TWO sets of operand fragments, so the
+// fragments of the next half-step are read while the MFMAs of the current one run -- inside one wave, without relying on
+// a second wave of the SIMD being out of phase.  One barrier per K-step, in its middle:
+//     first half : MFMAs on F0 = fragments (t, k 0..31)   | read F1 = (t, k 32..63)
+//     lgkmcnt(0), vmcnt(8), barrier                        -> every wave is done with step t's slots; step t+1 has landed
+//     second half: MFMAs on F1                             | copy W(t+2), X(t+3) into the freed slots | read F0 = (t+1, k 0..31)
+// Ring as in gemm_x3_kernel (X: 3 slots, two steps ahead; W: 2 slots).  Copies, reads and MFMAs are laid out in 16 groups
+// per half-step (1 copy, 1 read, 4 MFMAs) fenced by sched_barrier, so the issue order is the one written here.
+template <class T, int EPI, int ABL = 0>     // ABL (HM_ABLATIONS builds only): 1 = no copies in the loop, 2 = copies and waits only
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const KArgs g) {
+  constexpr int MI = 8, NI = 8, BM = 256, BN = 256, BK = 64, ROWB = 128;
+  constexpr int TILE_BYTES = 256 * ROWB;
+  constexpr int XRING = 0, WRING = 3 * TILE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using vec8 = typename T::vec8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wr = wave >> 1, wc = wave & 1;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+
+  // copies: wave w moves rows [64 w, 64 w + 64) of both tiles, 8 pieces of 8 rows x 128 B each
+  const int srow = lane >> 3, swz = (lane & 7) ^ (srow & 7);
+  unsigned xoff[8], woff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int gm = m0 + wave * 64 + i * 8 + srow;
+    gm = gm < g.M ? gm : g.M - 1;
+    xoff[i] = (unsigned)gm * (unsigned)(g.ldx * 2) + swz * 16;
+    int gn = n0 + wave * 64 + i * 8 + srow;
+    gn = gn < g.N ? gn : g.N - 1;
+    woff[i] = (unsigned)gn * (unsigned)(g.ldw * 2) + swz * 16;
+  }
+  auto dma_x1 = [&](int slot, int kt, int i) { glds16_hidden_s(X + (size_t)kt * ROWB, xoff[i], smem + XRING + slot * TILE_BYTES + (wave * 8 + i) * 1024); };
+  auto dma_w1 = [&](int slot, int kt, int i) { glds16_hidden_s(W + (size_t)kt * ROWB, woff[i], smem + WRING + slot * TILE_BYTES + (wave * 8 + i) * 1024); };
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fsw = lane & 7, fch = lane >> 4;
+  const int fx = (wr * 128 + frow) * ROWB, fw = (wc * 128 + frow) * ROWB;
+  const int c0 = (fch ^ fsw) * 16, c1 = ((4 + fch) ^ fsw) * 16;
+  vec8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
+  // fragment j of a half-step: j < 8 -> X rows 16 j.., else W rows 16 (j - 8)..
+  auto rd = [&](const char* lx, const char* lw, int coff, int j, vec8 (&wf)[NI], vec8 (&xf)[MI]) {
+    if constexpr (ABL == 2) return;
+    if (j < 8) xf[j] = *(const vec8*)(lx + fx + j * 16 * ROWB + coff);
+    else wf[j - 8] = *(const vec8*)(lw + fw + (j - 8) * 16 * ROWB + coff);
+  };
+  auto mma4 = [&](int j, const vec8 (&wf)[NI], const vec8 (&xf)[MI]) {      // group j of 16: W fragment j / 2, X fragments 4 (j & 1) .. + 3
+    if constexpr (ABL == 2) return;
+    const int ni = j >> 1, mb = (j & 1) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[ni][mb + q] = T::mfma(wf[ni], xf[mb + q], acc[ni][mb + q]);
+  };
+
+  const int nk = g.K / BK;                              // host: nk >= 3
+  // prologue: X(0) W(0) X(1) W(1) X(2)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_x1(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_w1(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_x1(1, 1, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_w1(1, 1, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_x1(2, 2, i);
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");    // X(0), W(0)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) rd(smem + XRING, smem + WRING, c0, j, wf0, xf0);
+
+  int xs = 0;                                          // X slot of step t (t % 3); W slot t & 1
+  // one K-step; CW / CX: copies of W(t+2) / X(t+3) exist, MORE: a step t+1 exists (compile-time: the steady-state body has no branch)
+  auto step = [&](auto CW, auto CX, auto MORE, int t) {
+    const char* lx = smem + XRING + xs * TILE_BYTES;
+    const char* lw = smem + WRING + (t & 1) * TILE_BYTES;
+    // ---- first half
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      rd(lx, lw, c1, j, wf1, xf1);
+      mma4(j, wf0, xf0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // F1 is in registers (this wave is done with step t's slots); all but X(t+2) of this wave's copies have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (decltype(CW)::value && ABL != 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- second half
+    const int xn = xs == 2 ? 0 : xs + 1;               // slot of step t + 1
+    const char* lx1 = smem + XRING + xn * TILE_BYTES;
+    const char* lw1 = smem + WRING + ((t + 1) & 1) * TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < 8) { if constexpr (decltype(CW)::value && ABL != 1) dma_w1(t & 1, t + 2, j); }            // W first, then X: the counted wait relies on this order
+      else { if constexpr (decltype(CX)::value && ABL != 1) dma_x1(xs, t + 3, j - 8); }
+      if constexpr (decltype(MORE)::value) rd(lx1, lw1, c0, j, wf0, xf0);
+      mma4(j, wf1, xf1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    xs = xn;
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
+  for (int t = 0; t < nk - 3; ++t) step(Yes{}, Yes{}, Yes{}, t);
+  step(Yes{}, No{}, Yes{}, nk - 3);
+  step(No{}, No{}, Yes{}, nk - 2);
+  step(No{}, No{}, No{}, nk - 1);
+
+  __builtin_amdgcn_s_barrier();                        // the ring is free: per-column vectors, then epilogue staging
+  constexpr int EPI_BYTES = 4 * epi_stage_bytes(MI, NI);
+  float2* rowstat = (float2*)(smem + EPI_BYTES);       // unused by these epilogues
+  float* colvec = (float*)(rowstat + BM);
+  colvec[tid] = g.bias ? g.bias[min(n0 + tid, g.N - 1)] : 0.f;
+  __builtin_amdgcn_s_barrier();
+  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 128, n0 + wc * 128, lane, smem + wave * epi_stage_bytes(MI, NI),
+                           rowstat + wr * 128, colvec + wc * 128, colvec + BN + wc * 128, 0);
+}
+
+template <class T, int EPI, int ABL = 0>
+int launch_w4(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 5 * 256 * 128;
+  static_assert(LDS >= 4 * epi_stage_bytes(8, 8) + 256 * 8 + 2 * 256 * 4, "epilogue staging + vectors fit");
+  auto kern = gemm_w4_kernel<T, EPI, ABL>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, s, g);
+  return hm_check_launch("hm_gemm");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Persistent form of gemm_fp8_kernel (the gemm_px_kernel idea on the fp8 MFMA) for the qkv (bf16 out) and fc1 (GELU ->
 // MXFP8 out) GEMMs of BASELINE configs[4].  An fp8 K-step carries twice the flops of a 16-bit one, so a K = 1280 tile is
 // only 10 steps (~15 us) and the per-tile start-up / drain of the one-tile kernel is ~40 % of its time at B = 256.
@@ -1398,6 +1542,8 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 10: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");  // + loads issued between the two sub-steps
     case 11: return launch_cfg<T, EPI, 4, 2, 4, 8, 4, false, 32, 1>(g, s, "hm_gemm");  // 256x256x32, 4 stages, setprio
 #ifdef HM_ABLATIONS   // timing ablations with WRONG results: only in a -DHM_ABLATIONS build (tools/bench_gemm_ab.py), never in the shipped library
+    case 30: if constexpr (EPI == HM_EPI_STORE) return launch_w4<T, EPI, 1>(g, s); else return hm_set_error(HM_ERR_ARG, "ablation"); // w4 without copies
+    case 31: if constexpr (EPI == HM_EPI_STORE) return launch_w4<T, EPI, 2>(g, s); else return hm_set_error(HM_ERR_ARG, "ablation"); // w4 copies only
     case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // LDS-DMA + waits + barriers only
     case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ds_read + MFMA + barriers, no loads
     case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // no epilogue
@@ -1410,6 +1556,11 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 28:                                                                           // EXPERIMENT: 256x160, both operands two steps ahead
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
         if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_d2<T, EPI>(g, s);
+      }
+      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
+    case 29:                                                                           // 256x256 on four waves of 128x128 (gemm_w4_kernel)
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
+        if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32) && g.K >= 192) return launch_w4<T, EPI>(g, s);
       }
       return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
     case 26:                                                                           // persistent 256x256 (gemm_px_kernel), else as 24
@@ -1444,9 +1595,9 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1) return true;
 #ifdef HM_ABLATIONS
-  if (v == 14 || v == 15 || v == 18 || v == 20) return true;
+  if (v == 14 || v == 15 || v == 18 || v == 20 || v == 30 || v == 31) return true;
 #endif
-  return (v >= 0 && v <= 11) || (v >= 21 && v <= 26) || v == 28;
+  return (v >= 0 && v <= 11) || (v >= 21 && v <= 26) || v == 28 || v == 29;
 }
 
 int pick_variant(const KArgs& g) {

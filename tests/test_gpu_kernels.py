@@ -124,7 +124,7 @@ def test_gemm_persistent_kernel_exact(dt):
         lib.hm_gemm_set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [25, 28])
+@pytest.mark.parametrize("variant", [25, 28, 29])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gemm_256x320_tile_exact(dt, variant):
     """Variant 25 (256x320 tile) and variant 28 (256x160 tile, both operands two K-steps ahead in three-slot rings, hand-counted

@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamer_yolo_amd import lib as L
 from hamer_yolo_amd import ops
 
+if os.environ.get("ABLATION_LIB"):     # python -m hamer_yolo_amd.build --ablations: variants that skip work (wrong results, timing only)
+    L.LIB_PATH = L.LIB_PATH.replace(".so", "_abl.so")
+
 variants = [int(v) for v in os.environ.get("VARIANTS", "0,8").split(",")]      # v >= 100: default variant with group_m = v - 100
 rounds, reps = int(os.environ.get("ROUNDS", 6)), int(os.environ.get("REPS", 5))
 M = int(os.environ.get("BATCH", 64)) * 192
@@ -22,6 +25,8 @@ shapes = [("qkv", 1280, 3840, L.HM_EPI_STORE), ("proj", 1280, 1280, L.HM_EPI_RES
           ("fc2", 5120, 1280, L.HM_EPI_RESID_F32), ("kv", 1280, 6144, L.HM_EPI_STORE)]
 if ONLY:
     shapes = [sh for sh in shapes if sh[0] in ONLY]
+if os.environ.get("EPI_STORE"):                # every shape with the plain 16-bit store epilogue (K-loop comparisons)
+    shapes = [(n, k, nn, L.HM_EPI_STORE) for (n, k, nn, _) in shapes]
 lib = L.load()
 res = {}
 
@@ -53,6 +58,18 @@ for (name, K, N, epi) in shapes:
                     ops.gemm(x, w, b, epi, resid=r, out=out)
                 torch.cuda.synchronize()
             times[v] += [rec[5] for rec in prof.records]
+    if os.environ.get("YARDSTICK"):           # the vendor library on the same operands (plain x @ w.T + b, 16-bit out): a yardstick, not a product path
+        lin = lambda: torch.nn.functional.linear(x.contiguous(), w.contiguous(), b.to(DT))
+        xc, wc, bc = x.contiguous(), w.contiguous(), b.to(DT)
+        for _ in range(3):
+            torch.nn.functional.linear(xc, wc, bc)
+        ts = []
+        for _ in range(rounds * reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); torch.nn.functional.linear(xc, wc, bc); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort(); med = ts[len(ts) // 2]
+        print(f"{name:5s} hipBLASLt (torch linear, bias, 16-bit out) median {med*1e3:7.1f} us  min {ts[0]*1e3:7.1f}  {2.0*M*N*K/med/1e9:7.1f} TF", flush=True)
     for v in variants:
         t = sorted(times[v]); med = t[len(t) // 2]
         res[(name, v)] = med
