@@ -12,6 +12,11 @@ OUT=gpurun_out
 mkdir -p $OUT/prof_$TAG $OUT/pmc_$TAG
 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o ${TAG} --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_$TAG/bench_under_rocprof.log 2>&1 || exit 1
 tail -c 300 $OUT/prof_$TAG/bench_under_rocprof.log
+# the same bench with ONE batch in flight: per-kernel durations free of the other stream (what bench.py's event-timed pass
+# measures; under two batches in flight a kernel's start-to-end time includes waiting for CUs the other stream holds)
+mkdir -p $OUT/prof_${TAG}_serial
+rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_serial -o ${TAG}_serial --output-format csv -- python3 bench.py --steps 10 --warmup 3 --in-flight 1 --no-cpu-baseline > $OUT/prof_${TAG}_serial/bench_under_rocprof.log 2>&1 || exit 1
+tail -c 300 $OUT/prof_${TAG}_serial/bench_under_rocprof.log
 for pass in fetch write mfma; do
   case $pass in
     fetch) PMC="FETCH_SIZE" ;;
