@@ -101,12 +101,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // n-subtiles per epilogue column group: the largest divisor of NI that keeps a wave's staging within 16 KB (<= 16 / MI)
-constexpr int epi_cgn(int MI, int NI) {
-  int c = NI < 16 / MI ? NI : 16 / MI;
+constexpr int epi_cgn(int MI, int NI, int KB = 16) {
+  int c = NI < KB / MI ? NI : KB / MI;
   while (NI % c != 0) --c;
   return c;
 }
-constexpr int epi_stage_bytes(int MI, int NI) { return MI * 16 * epi_cgn(MI, NI) * 64; }
+constexpr int epi_stage_bytes(int MI, int NI, int KB = 16) { return MI * 16 * epi_cgn(MI, NI, KB) * 64; }
 
 // Epilogue of one wave through LDS.  acc[ni][mi] holds C[mb + mi*16 + (lane&15)][nb + ni*16 + 4*(lane>>4) .. +3]
 // (the MFMA accumulator layout: 16 rows x 16-byte pieces per store).  Written straight from that layout every
@@ -134,13 +134,13 @@ __device__ __forceinline__ float row8_sum(float v) {
   return v;
 }
 
-template <class T, int EPI, int MI, int NI, bool RESID_REGS = true>
+template <class T, int EPI, int MI, int NI, bool RESID_REGS = true, int STAGE_KB = 16>
 __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI], int mb, int nb, int lane, char* wlds,
                                          const float2* rowstat, const float* cbias, const float* cvec2, int split) {
   using elem = typename T::elem;
   // n-subtiles per column group: <= 16 KB of LDS per wave; the residual epilogue splits that between the
   // transposed accumulators and the residual rows, which arrive by LDS-DMA (no registers, all in flight at once)
-  constexpr int CGN0 = epi_cgn(MI, NI);
+  constexpr int CGN0 = epi_cgn(MI, NI, STAGE_KB);
   constexpr bool LNOUT = EPI == HM_EPI_RESID_LN, LNIN = epi_ln_in(EPI);
   constexpr bool RESREG = EPI == HM_EPI_RESID_F32 && RESID_REGS;   // residual rows prefetched into registers, one column group ahead
   constexpr bool RES = LNOUT || (EPI == HM_EPI_RESID_F32 && !RESID_REGS);   // residual rows through LDS (deferred-LN producer; fp8 kernel: no registers to spare)
@@ -490,7 +490,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     if (s < nk) stage(s, s);
   // deferred-LN consumer: (mean, rstd) of this tile's rows from the producer's 64-column partials, kept in LDS past
   // the ring; the K loop's barriers order these writes before the epilogue reads
-  constexpr int RING_BYTES = STAGES * STAGE_BYTES, EPI_BYTES = NW * epi_stage_bytes(MI, NI);
+  constexpr int SKB = NW > 8 ? 8 : 16;                 // sixteen waves: 8 KB of epilogue staging each
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES, EPI_BYTES = NW * epi_stage_bytes(MI, NI, SKB);
   float2* rowstat = (float2*)(smem + (RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES));
   float* colvec = (float*)(rowstat + BM);              // [2][BN]: bias (or zeros) | ln_gamma or ln_colsum
   for (int c = tid; c < BN; c += 64 * NW) {
@@ -505,9 +506,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   int rd = 0, wrb = STAGES - 1;                        // ring slots: read tile kt, write tile kt+STAGES-1
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed: in steady state the STAGES-2 newer tiles may still be in flight
-    if (kt + STAGES - 2 < nk) wait_vmcnt<LOADS * (STAGES - 2)>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                      // everyone's tile kt landed; everyone is done reading slot wrb
+    if (SCHED != 94 && SCHED != 95) {                  // (ablations 94 / 95: nobody waits for the copies; 95: no barrier either)
+      if (kt + STAGES - 2 < nk) wait_vmcnt<LOADS * (STAGES - 2)>();
+      else wait_vmcnt<0>();
+    }
+    if (SCHED != 95) __builtin_amdgcn_s_barrier();     // everyone's tile kt landed; everyone is done reading slot wrb
     const bool more = kt + STAGES - 1 < nk;
     if (SCHED <= 1) {                                  // loads first, then the whole tile
       if (more) stage(wrb, kt + STAGES - 1);
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
       for (int b = 0; b < MI; ++b) asm volatile("" :: "v"(acc[a][b]));
     return;
   }
-  epilogue<T, EPI, MI, NI>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI),
+  epilogue<T, EPI, MI, NI, true, SKB>(g, acc, m0 + wr * 16 * MI, n0 + wc * 16 * NI, lane, smem + wave * epi_stage_bytes(MI, NI, SKB),
                            rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI, split);
 }
 
@@ -1511,7 +1514,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
 template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
 int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
-  constexpr int RING = STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI);
+  constexpr int RING = STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI, WM * WN > 8 ? 8 : 16);
   constexpr int LDS = (RING > EPIB ? RING : EPIB) + BM * 8 + BN * 8;     // + row statistics + column vectors
   auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED>;
   static HmLdsOnce lds_once;
@@ -1544,11 +1547,14 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
 #ifdef HM_ABLATIONS   // timing ablations with WRONG results: only in a -DHM_ABLATIONS build (tools/bench_gemm_ab.py), never in the shipped library
     case 30: if constexpr (EPI == HM_EPI_STORE) return launch_w4<T, EPI, 1>(g, s); else return hm_set_error(HM_ERR_ARG, "ablation"); // w4 without copies
     case 31: if constexpr (EPI == HM_EPI_STORE) return launch_w4<T, EPI, 2>(g, s); else return hm_set_error(HM_ERR_ARG, "ablation"); // w4 copies only
+    case 16: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 94>(g, s, "hm_gemm"); // everything, but no wave waits for its copies
+    case 17: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 95>(g, s, "hm_gemm"); // ... and no barrier
     case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // LDS-DMA + waits + barriers only
     case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ds_read + MFMA + barriers, no loads
     case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // no epilogue
     case 18: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 97>(g, s, "hm_gemm"); // every tile loads operand panel 0 (pure L2 hits)
 #endif
+    case 12: return launch_cfg<T, EPI, 4, 4, 4, 4, 2, false, 64, 2>(g, s, "hm_gemm");  // 256x256 on SIXTEEN waves of 64x64 (4 per SIMD, <= 128 VGPRs), 2 stages
     case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
     case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
     case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
@@ -1595,9 +1601,9 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1) return true;
 #ifdef HM_ABLATIONS
-  if (v == 14 || v == 15 || v == 18 || v == 20 || v == 30 || v == 31) return true;
+  if ((v >= 14 && v <= 18) || v == 20 || v == 30 || v == 31) return true;
 #endif
-  return (v >= 0 && v <= 11) || (v >= 21 && v <= 26) || v == 28 || v == 29;
+  return (v >= 0 && v <= 12) || (v >= 21 && v <= 26) || v == 28 || v == 29;
 }
 
 int pick_variant(const KArgs& g) {

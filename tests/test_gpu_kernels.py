@@ -43,7 +43,7 @@ def test_gemm_exact_integers_asymmetric():
         assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("variant", list(range(12)))
+@pytest.mark.parametrize("variant", list(range(13)))
 def test_gemm_tile_variants_exact(variant):
     """Every tile / pipeline configuration of gemm.hip on exact-integer data (bit-exact whatever the
     summation order), ragged M and N, several K-tile counts (ring prologue / steady state / tail)."""
