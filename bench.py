@@ -117,10 +117,19 @@ def run_e2e(args, dev, dtype):
             Image.fromarray(synth.frame_u8(1080, 1920, seed=i % 8).numpy()[:, :, ::-1]).save(os.path.join(in_dir, f"f{i:04d}.bmp"))
         hi = infer.hamer_inference(HCfg)
         det = Detector(YCfg)
+        sar, k_real = None, None
+        if args.workload == "e2e-depth":                   # d_infer.py: + RootNet root depth per hand
+            from hamer_yolo_amd import d_infer
+            from hamer_yolo_amd.rootnet.Model_RGB import get_model
+            sar = get_model()                              # synthetic ResNet-34 + depth head (rootnet/sar_config_stage_1.py)
+            k_real = np.array([[1400.0, 0, 960], [0, 1400.0, 540], [0, 0, 1]], np.float32)
 
         def step():
             shutil.rmtree(out_dir, ignore_errors=True)
-            infer.process_batch_manopara(in_dir, out_dir, None, hamer=hi, detector=det, frames_per_step=F)
+            if sar is not None:
+                d_infer.process_batch_manopara(in_dir, out_dir, k_real, hamer=hi, detector=det, sar=sar, frames_per_step=F)
+            else:
+                infer.process_batch_manopara(in_dir, out_dir, None, hamer=hi, detector=det, frames_per_step=F)
 
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
@@ -143,8 +152,10 @@ def run_e2e(args, dev, dtype):
                       "hands_per_frame": round(hands / n_frames, 2), "frames_per_s": round(n_frames * args.steps / el, 2),
                       "npy_files_per_pass": files, "higher_is_better": True,
                       "dtype": args.dtype + " (HaMeR) / fp16 (YOLOv7)", "data": "synthetic",
-                      "config": {"workload": "BASELINE configs[2]: 1080p frames through yolo/detector.py YOLOv7 + HaMeR via "
-                                             "infer.process_batch_manopara (the README entry point), detector boxes used as found",
+                      "config": {"workload": ("d_infer.py flow: 1080p frames through YOLOv7 + RootNet (ResNet-34 root depth per hand) + HaMeR via "
+                                              "d_infer.process_batch_manopara, detector boxes used as found") if sar is not None else
+                                             ("BASELINE configs[2]: 1080p frames through yolo/detector.py YOLOv7 + HaMeR via "
+                                              "infer.process_batch_manopara (the README entry point), detector boxes used as found"),
                                  "frames_per_step": F, "chunks_in_flight": 2},
                       "gflop_per_frame": round(61.9 + hands / n_frames * 251.03, 1)}), flush=True)
 
@@ -191,7 +202,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp8"],
                     help="GEMM operand type.  fp16 (default) meets the 1e-3 parity bar on fp32 master weights, bf16 does not "
                          "(DESIGN.md section 2); fp8: BASELINE configs[4] (qkv/proj/fc1/fc2 on the fp8 MFMA), use with --batch 256")
-    ap.add_argument("--workload", default="crops", choices=["crops", "shard1024", "e2e"],
+    ap.add_argument("--workload", default="crops", choices=["crops", "shard1024", "e2e", "e2e-depth"],
                     help="crops: BASELINE configs[1] (default, the contract line; weak scaling: --batch crops per GPU per step); "
                          "shard1024: configs[3], 1024 crops in all, ceil(1024/N) per GPU in forwards of --batch, MANO parameters "
                          "gathered to rank 0 (strong scaling; a step = the whole 1024-crop job); e2e: configs[2], 1080p frames on "
@@ -222,7 +233,7 @@ def main():
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     B = args.batch
 
-    if args.workload == "e2e":
+    if args.workload in ("e2e", "e2e-depth"):
         return run_e2e(args, dev, dtype)
 
     # weights: rank 0 draws the synthetic checkpoint (fp32 master weights), RCCL broadcasts it as two flat buffers

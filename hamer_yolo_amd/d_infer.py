@@ -8,49 +8,31 @@ import os
 import numpy as np
 
 from .infer import *  # noqa: F401,F403
-from .infer import (_detection_list, _imread_bgr, _list_images, hamer_inference, hamer_opt, hand_record, load_intrinsics,  # noqa: F401
-                    reconstruct_and_save_obj_with_wrapper)
+from .infer import (FRAMES_PER_STEP, _default_models, _detection_list, _imread_bgr, _list_images, _record_from, hamer_inference,  # noqa: F401
+                    hamer_opt, hand_record, iter_folder_results, load_intrinsics, reconstruct_and_save_obj_with_wrapper)
 from .rootnet.Model_RGB import get_model  # noqa: F401
 
 
-def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None, detector=None, sar=None):
+def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None, detector=None, sar=None,
+                           frames_per_step: int = FRAMES_PER_STEP):
     """d_infer.py:1223-1318: as infer.py's, with the RootNet depth per hand.  ``k_real`` is required here (the depth is
-    metric only with real intrinsics; the reference passes its camera file).  One RootNet and one HaMeR forward per hand, as in
-    the reference (each hand's camera translation uses its own depth)."""
+    metric only with real intrinsics; the reference passes its camera file).  The reference runs one RootNet and one HaMeR
+    forward per hand; here the folder goes through infer.py's chunked two-stream pipeline with ONE RootNet forward and ONE
+    HaMeR forward per chunk of frames -- each hand's camera translation still uses its own depth (``depth_refine`` is a
+    per-hand vector in the camera step), and the numbers are those of the one-hand calls."""
     os.makedirs(output_folder, exist_ok=True)
     if k_real is None:
         raise ValueError("d_infer needs camera intrinsics (k_real)")
-    if hamer is None:
-        hamer = hamer_inference(hamer_opt)
-    if detector is None:
-        from .config.yolo_config import yolo_opt
-        from .yolo.detector import Detector
-        detector = Detector(yolo_opt)
+    hamer, detector = _default_models(hamer, detector)
     if sar is None:
         sar = get_model()
-    for img_path in _list_images(input_folder):
+    for img_path, detection_list, hands in iter_folder_results(_list_images(input_folder), hamer, detector, k_real, frames_per_step,
+                                                               depth_model=sar):
         file_name = os.path.splitext(os.path.basename(img_path))[0]
         image_results = {'left': None, 'right': None}
-        try:
-            image = _imread_bgr(img_path)
-            if image is None:
-                continue
-            _, dets = detector.detect(image)
-            detection_list = _detection_list(dets)
-            if not detection_list:
-                continue
-            for bbox in detection_list:
-                try:
-                    depth_pred = sar.estimate_root_depth_custom(image, k_real, bbox[1])
-                    output, _ = hamer.estimate_from_rgb(image, [bbox], k_real, depth_refine=depth_pred)
-                    image_results[bbox[0]] = hand_record(output, bbox[0] == 'right', 0)
-                except Exception as e:
-                    print(f"Error processing hand in {file_name}: {e}")
-                    continue
-            np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
-        except Exception as e:
-            print(f"Error processing file {img_path}: {e}")
-            continue
+        for i, bbox in enumerate(detection_list):
+            image_results[bbox[0]] = _record_from(hands, i, bbox[0] == 'right')
+        np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
 
 
 def main(argv=None):

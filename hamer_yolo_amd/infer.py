@@ -331,10 +331,13 @@ FRAMES_PER_STEP = 16
 
 
 def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_step: int = FRAMES_PER_STEP, in_flight: int = 2,
-                        decode_threads: Optional[int] = None):
+                        decode_threads: Optional[int] = None, depth_model=None):
     """Yields ``(path, detection_list, hands)`` per image that has detections, in path order; ``hands`` is a dict of host
     numpy arrays for that image's hands in detection order: betas (n,10), global_orient (n,1,3,3), hand_pose (n,15,3,3),
-    cam_t (n,3), do_flip (n,), plus the axis-angle forms pose_global (n,3) and pose_hand (n,45)."""
+    cam_t (n,3), do_flip (n,), plus the axis-angle forms pose_global (n,3) and pose_hand (n,45).
+    ``depth_model`` (d_infer): a RootNet ``EstimateRGB``; every hand's root depth comes from ONE RootNet forward per chunk
+    and enters the camera step as its ``depth_refine``; hands without a RootNet patch are dropped, as the reference's
+    per-hand try/except drops them."""
     from concurrent.futures import ThreadPoolExecutor
     dev = hamer.device
     nthreads = decode_threads or max(1, min(16, len(os.sched_getaffinity(0))))
@@ -384,10 +387,17 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             else:                                              # any object with the reference's detect(image) works too
                 dets_lists = [detector.detect(im)[1] for _, im in chunk]
             dets_lists = [[d for d in _detection_list(dl) if box_has_area(d)] for dl in dets_lists]
+            if depth_model is not None:
+                for i, (fr, dl) in enumerate(zip(frames, dets_lists)):
+                    ok = depth_model.valid_boxes(dl, int(fr.shape[1]), int(fr.shape[0]))
+                    dets_lists[i] = [d for d, v in zip(dl, ok) if v]
             keep = [i for i, d in enumerate(dets_lists) if d]
             if not keep:
                 return None
-            out, _ = hamer.estimate_from_frames([frames[i] for i in keep], [dets_lists[i] for i in keep], k_real)
+            depth = None
+            if depth_model is not None:
+                depth = depth_model.estimate_root_depths_frames([frames[i] for i in keep], k_real, [dets_lists[i] for i in keep])
+            out, _ = hamer.estimate_from_frames([frames[i] for i in keep], [dets_lists[i] for i in keep], k_real, depth_refine=depth)
             mp = out['pred_mano_params']
             dev_res = {'betas': mp['betas'], 'global_orient': mp['global_orient'], 'hand_pose': mp['hand_pose'],
                        'cam_t': out['pred_cam_t_full'], 'do_flip': out['do_flip']}

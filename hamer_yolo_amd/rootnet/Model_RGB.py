@@ -10,7 +10,7 @@ import torch
 from .. import lib as L
 from .. import ops, synth
 from .engine import RootNetEngine
-from .preprocessing import process_bbox
+from .preprocessing import patch_boxes, process_bbox
 
 
 class EstimateRGB:
@@ -36,11 +36,14 @@ class EstimateRGB:
         self.mean = 255.0 * np.array([0.485, 0.456, 0.406])
         self.std = 255.0 * np.array([0.229, 0.224, 0.225])
 
-    def calculate_k(self, bbox, fx, fy):
-        """Model_RGB.py:494-498: sqrt(real_area * fx * fy / bbox_area), shape (1,)."""
+    def _k_host(self, bbox, fx, fy):
         area = bbox[-1] * bbox[-2]
         real_area = torch.tensor(self.cfg.bbox_real[0] * self.cfg.bbox_real[1])
-        return torch.sqrt(real_area * fx * fy / (area)).unsqueeze(0).to(self.device)
+        return torch.sqrt(real_area * fx * fy / (area)).unsqueeze(0)
+
+    def calculate_k(self, bbox, fx, fy):
+        """Model_RGB.py:494-498: sqrt(real_area * fx * fy / bbox_area), shape (1,)."""
+        return self._k_host(bbox, fx, fy).to(self.device)
 
     def patch(self, img: np.ndarray, bbox_processed) -> torch.Tensor:
         """generate_patch_image + BGR->RGB + ToTensor + Normalize (:596-610) for one box, on the GPU."""
@@ -61,6 +64,48 @@ class EstimateRGB:
         k_value = self.calculate_k(bbox_processed, float(fx), float(fy))
         depth = self.engine.forward(self.patch(img, bbox_processed), k_value)
         return depth.item()
+
+
+    # -------------------------------------------------------------------------------- batched form (d_infer's folder driver)
+    def valid_boxes(self, dets, width, height):
+        """Which detections [[label, [x1, y1, x2, y2]], ...] of a width x height frame have a RootNet patch at all (the ones
+        estimate_root_depth_custom would raise on -- the reference's per-hand try/except skips those hands)."""
+        if not dets:
+            return np.zeros(0, dtype=bool)
+        xywh = np.array([[d[1][0], d[1][1], d[1][2] - d[1][0], d[1][3] - d[1][1]] for d in dets], dtype=np.float64)
+        return patch_boxes(xywh, width, height, self.cfg.input_img_shape, 1.5)[1]
+
+    @torch.no_grad()
+    def estimate_root_depths_frames(self, frames, K, dets_lists) -> torch.Tensor:
+        """estimate_root_depth_custom for ALL hands of several device-resident frames ((H,W,3) uint8 BGR tensors) in one
+        RootNet forward: one crop launch per frame into one batch tensor, one pass of the backbone.  Per hand the same
+        box arithmetic, the same crop and the same k as the one-hand call, so the depths are the same numbers.  Every
+        detection must have a patch (filter with valid_boxes first).  Returns (n,) fp32 on the device, hands in
+        ``dets_lists`` order."""
+        fx, fy = (K[0, 0], K[1, 1]) if isinstance(K, np.ndarray) else (K[0][0], K[1][1])
+        P = int(self.cfg.input_img_shape[0])
+        recs, kvs, counts = [], [], []
+        for fr, dets in zip(frames, dets_lists):
+            height, width = int(fr.shape[0]), int(fr.shape[1])
+            for _, (x1, y1, x2, y2) in dets:
+                bp = process_bbox([x1, y1, x2 - x1, y2 - y1], width, height, self.cfg.input_img_shape, 1.5)
+                if bp is None:
+                    raise ValueError("empty bounding box")
+                recs.append((float(bp[0] + 0.5 * bp[2]), float(bp[1] + 0.5 * bp[3]), float(bp[2]), False))
+                kvs.append(self._k_host(bp, float(fx), float(fy)))          # host arithmetic (correctly rounded ops: the same bits), one upload
+            counts.append(len(dets))
+        n = len(recs)
+        if n == 0:
+            return torch.empty(0, device=self.device)
+        rec = ops.crop_boxes(recs, P).to(self.device)
+        rsz = rec.numel() // n
+        img = torch.empty(n, 3, P, P, device=self.device, dtype=torch.float32)
+        off = 0
+        for fr, k in zip(frames, counts):
+            if k:
+                ops.crop_batch(fr, rec[off * rsz:(off + k) * rsz], self.mean, self.std, P, out=img[off:off + k])
+                off += k
+        return self.engine.forward(img, torch.cat(kvs))
 
 
 def get_model():

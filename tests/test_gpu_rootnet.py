@@ -114,3 +114,57 @@ def test_d_infer_batch_driver(tmp_path):
         np.testing.assert_allclose(rec[label]["cam_t"][2], depth, rtol=1e-5)
     with pytest.raises(ValueError):
         d_infer.process_batch_manopara(str(tmp_path / "rgb"), str(tmp_path / "out2"), None, hamer=hi, detector=_Det(dets), sar=sar)
+
+
+def test_d_infer_chunked_driver_equals_one_hand_calls(tmp_path):
+    """The folder driver of d_infer runs ONE RootNet forward and ONE HaMeR forward per chunk of frames; per hand it must
+    save what the reference's flow (one estimate_root_depth_custom + one estimate_from_rgb(depth_refine=...) per hand,
+    d_infer.py:1268-1304) produces: three frames of two sizes, several hands each, one box that has no RootNet patch (dropped,
+    as the reference's per-hand try/except drops it), one frame without detections (no file)."""
+    from PIL import Image
+    from hamer_yolo_amd import d_infer
+    from hamer_yolo_amd.infer import hand_record
+    from hamer_yolo_amd.rootnet.Model_RGB import get_model
+
+    class _Cfg:
+        ckpt_path = "synthetic:0"; model_cfg = None; use_onnx = False; onnx_path = None
+
+    frames = {"a": synth.frame_u8(480, 640, seed=8).numpy(), "b": synth.frame_u8(480, 640, seed=9).numpy(),
+              "c": synth.frame_u8(720, 1280, seed=10).numpy(), "d": synth.frame_u8(480, 640, seed=11).numpy()}
+    dets = {"a": [["right", [100.0, 120.0, 260.0, 300.0]], ["left", [380.0, 200.0, 520.0, 330.0]]],
+            "b": [["left", [30.0, 40.0, 200.0, 260.0]], ["right", [600.0, 100.0, 640.0, 101.0]], ["right", [300.0, 220.0, 420.0, 400.0]]],
+            "c": [["right", [900.0, 300.0, 1150.0, 560.0]]], "d": []}
+    # (b's second box is 1 pixel high: it has area for HaMeR's crop but clips to nothing in RootNet's box arithmetic)
+
+    class _Det:
+        def detect(self, image):
+            for k, f in frames.items():
+                if f.shape == image.shape and np.array_equal(f, image):
+                    return [None], [dets[k]]
+            raise AssertionError("unknown frame")
+    (tmp_path / "rgb").mkdir()
+    for k, f in frames.items():
+        Image.fromarray(f[:, :, ::-1]).save(tmp_path / "rgb" / f"{k}.png")
+    K = np.array([[600.0, 0, 320], [0, 610.0, 240], [0, 0, 1]], np.float32)
+    sar = get_model()
+    hi = d_infer.hamer_inference(_Cfg)
+    assert not sar.valid_boxes(dets["b"], 640, 480)[1] and sar.valid_boxes(dets["b"], 640, 480)[[0, 2]].all()
+    d_infer.process_batch_manopara(str(tmp_path / "rgb"), str(tmp_path / "out"), K, hamer=hi, detector=_Det(), sar=sar)
+    assert sorted(p.name for p in (tmp_path / "out").iterdir()) == ["a.npy", "b.npy", "c.npy"]
+    for k in "abc":
+        rec = np.load(tmp_path / "out" / f"{k}.npy", allow_pickle=True).item()
+        want = {"left": None, "right": None}
+        for det in dets[k]:
+            try:
+                depth = sar.estimate_root_depth_custom(frames[k], K, det[1])
+            except ValueError:
+                continue
+            out, _ = hi.estimate_from_rgb(frames[k], [det], K, depth_refine=depth)
+            want[det[0]] = hand_record(out, det[0] == "right", 0)
+        for label in ("left", "right"):
+            assert (rec[label] is None) == (want[label] is None), (k, label)
+            if want[label] is None:
+                continue
+            assert rec[label]["is_right"] == want[label]["is_right"]
+            for key in ("betas", "theta", "cam_t"):
+                np.testing.assert_allclose(rec[label][key], want[label][key], rtol=1e-4, atol=2e-4, err_msg=f"{k} {label} {key}")   # (B = 1 and B = n forwards differ in fp32 summation order)
