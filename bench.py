@@ -146,7 +146,7 @@ def run_e2e(args, dev, dtype):
         files = len(glob.glob(os.path.join(out_dir, "*.npy")))
     finally:
         shutil.rmtree(root, ignore_errors=True)
-    print(json.dumps({"metric": "hands/sec end-to-end (files -> YOLOv7 -> crop -> HaMeR -> MANO -> .npy), 1080p frames",
+    print(json.dumps({"metric": "hands/sec end-to-end (files -> YOLOv7 -> " + ("RootNet depth + " if sar is not None else "") + "crop -> HaMeR -> MANO -> .npy), 1080p frames",
                       "value": round(hands * args.steps / el, 2), "unit": "hands/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": round(1e3 * el / args.steps, 3), "frames_per_pass": n_frames, "hands_per_pass": hands,
                       "hands_per_frame": round(hands / n_frames, 2), "frames_per_s": round(n_frames * args.steps / el, 2),
