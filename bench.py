@@ -160,6 +160,14 @@ def run_e2e(args, dev, dtype):
                       "gflop_per_frame": round(61.9 + hands / n_frames * 251.03, 1)}), flush=True)
 
 
+def tome_tokens(eng):
+    t, out = eng.tokens, []
+    for r in eng.tome_r:
+        t -= min(r, t // 2)
+        out.append(t)
+    return out
+
+
 def latest_profile(suffix: str):
     """profiles/rNN_<suffix> of the newest round that has one (the PMC passes are collected per round, tools/collect_profiles.sh)."""
     import glob
@@ -213,6 +221,8 @@ def main():
                     help="batches in flight: consecutive forwards alternate between this many HIP streams (own workspace and outputs "
                          "each), so one batch's HBM-bound phases overlap another's MFMA phases; 1 = strictly one after the other; "
                          "default 2")
+    ap.add_argument("--token-merge", action="store_true",
+                    help="HAMER_INFER(token_merge=True): ToMe with the reference's schedule r = (8, -1) (SURVEY 8f rank 4); not the contract line")
     ap.add_argument("--fold-ln", action="store_true", help="deferred LayerNorm (LN1/LN2 folded into the neighbouring GEMM epilogues)")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="force one GEMM tile variant (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -240,7 +250,8 @@ def main():
     sd0 = synth.hamer_state_dict(cfg, seed=0, device=dev) if rank == 0 else None
     sd = shard.broadcast_state_dict(sd0, dev, src=0, half_dtype=dtype) if world > 1 else sd0
     mano_cpu = synth.mano_params(seed=0)
-    eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype, fp8=(args.dtype == "fp8"), fold_ln=args.fold_ln or None)
+    eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype, fp8=(args.dtype == "fp8"), fold_ln=args.fold_ln or None,
+                      token_merge=True if args.token_merge else None)
     if args.gemm_variant >= 0:
         L.check(L.load().hm_gemm_set_variant(args.gemm_variant), "hm_gemm_set_variant")
     nfl = args.in_flight if args.in_flight > 0 else 2
@@ -338,6 +349,10 @@ def main():
                        "parallelism": f"crop-shard x{world}", "mfma_gflop_per_hand": round(fl["total_mfma"] / 1e9, 2)},
             "model_mfma_frac": round(hands / elapsed * fl["total_mfma"] / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         }
+        if args.token_merge:                # tokens are merged away block by block: the dense model's FLOP count does not apply
+            res["config"]["workload"] += "; ToMe token merging, r = (8, -1): tokens per crop after each block " + str(tome_tokens(eng))
+            res["config"]["mfma_gflop_per_hand"] = None
+            res["model_mfma_frac"] = None
         img = img if args.workload != "shard1024" else mine[:B].contiguous()
 
     # ---- roofline of the dominant kernel (the MFMA GEMM), HIP events on the launch stream
