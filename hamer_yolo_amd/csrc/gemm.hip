@@ -1301,10 +1301,10 @@ int launch_w4(const KArgs& g, hipStream_t s) {
 // counts around.  Whole tiles only (M, N multiples of 256; K >= 256).
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_fp8p_kernel(const KArgs g) {
-  static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU_MX8, "qkv / fc1 epilogues");
+  static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU_MX8 || EPI == HM_EPI_RESID_F32, "qkv / fc1 / proj, fc2 epilogues");
   constexpr int WN = 2, MI = 4, NI = 8, BM = 256, BKB = 128;
   constexpr int TILE_BYTES = 256 * BKB, SCALE_BYTES = 4 * BM, STAGE_BYTES = 2 * TILE_BYTES + SCALE_BYTES;
-  constexpr int NSTORE = EPI == HM_EPI_STORE ? 16 : 32;
+  constexpr int NSTORE = EPI == HM_EPI_STORE ? 16 : 32;             // stores per wave and tile (RESID_F32: 32 x 16 B of fp32)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1427,6 +1427,52 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8p_kernel(const KArgs g) {
     char* wl = stg + wave * 4096;
     const int arow = lane & 15, apiece = lane >> 4, row0 = lane >> 2, j = lane & 3;
     const int mb = m0 + wr * 64, nb = n0 + wc * 128;
+    if constexpr (EPI == HM_EPI_RESID_F32) {
+      // fp32 out = acc * wscale + bias + residual.  The residual rows of (column group, half-strip) g + 1 are requested --
+      // row-major, 2 x 16 B per lane and row, straight into registers the K loop no longer needs -- before group g is
+      // processed.  The loads are issued from asm (a load hipcc tracks makes it drain vmcnt to 0, with the next tile's
+      // copies and this tile's stores in flight) and waited for by count: newer than the loads of group g are the 4 stores
+      // of group g - 1 and the 4 loads of group g + 1.  The wait statement takes the four registers as read-write operands,
+      // so no use of them can be scheduled above it.  32 stores per wave (NSTORE).
+      f32x4_t rr[2][4];
+      auto rload = [&](int grp, f32x4_t (&dst)[4]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const float* p = g.resid + (size_t)(mb + (grp & 1) * 32 + it * 16 + row0) * g.ldr + nb + (grp >> 1) * 32 + 8 * j;
+          asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                       : "=&v"(dst[2 * it]), "=&v"(dst[2 * it + 1]) : "v"(p) : "memory");
+        }
+      };
+      rload(0, rr[0]);
+#pragma unroll
+      for (int grp = 0; grp < 8; ++grp) {
+        const int cg = grp >> 1, half = grp & 1;
+        if (grp + 1 < 8) rload(grp + 1, rr[(grp + 1) & 1]);
+        const f32x4_t b0 = *(const f32x4_t*)(cb + cg * 32 + 8 * j), b1 = *(const f32x4_t*)(cb + cg * 32 + 8 * j + 4);
+        const f32x4_t w0 = *(const f32x4_t*)(cb + 128 + cg * 32 + 4 * apiece), w1 = *(const f32x4_t*)(cb + 128 + cg * 32 + 16 + 4 * apiece);
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            const int row = mm * 16 + arow;
+            *(f32x4_t*)(wl + row * 128 + (((nl * 4 + apiece) ^ (row & 7)) << 4)) = acc[cg * 2 + nl][half * 2 + mm] * (nl ? w1 : w0);
+          }
+        f32x4_t (&r)[4] = rr[grp & 1];
+        if (grp == 0 || grp == 7) asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 16 + row0, sw = row & 7, m = mb + half * 32 + row, n = nb + cg * 32 + 8 * j;
+          f32x4_t v0 = *(const f32x4_t*)(wl + row * 128 + (((2 * j) ^ sw) << 4));
+          f32x4_t v1 = *(const f32x4_t*)(wl + row * 128 + (((2 * j + 1) ^ sw) << 4));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v0[q] = __fadd_rn(v0[q], b0[q]); v1[q] = __fadd_rn(v1[q], b1[q]); }
+          float* o = (float*)g.C + (size_t)m * g.ldc + n;
+          *(f32x4_t*)o = v0 + r[2 * it];
+          *(f32x4_t*)(o + 4) = v1 + r[2 * it + 1];
+        }
+      }
+    } else {
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) {
       const f32x4_t b0 = *(const f32x4_t*)(cb + cg * 32 + 8 * j), b1 = *(const f32x4_t*)(cb + cg * 32 + 8 * j + 4);
@@ -1472,6 +1518,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8p_kernel(const KArgs g) {
           }
         }
       }
+    }
     }
   }
 }
@@ -1752,7 +1799,12 @@ extern "C" int hm_gemm_fp8(const hm_gemm_fp8_args* a, void* stream_) {
       if (g.out_dtype != HM_DTYPE_BF16) return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: HM_EPI_STORE writes bf16 (out_dtype HM_DTYPE_BF16)");
       if (fp8p_ok(k) && (g.ldc & 7) == 0) return launch_fp8p<HM_EPI_STORE>(k, stream);
       return launch_fp8<HM_EPI_STORE>(k, stream);
-    case HM_EPI_RESID_F32: return launch_fp8<HM_EPI_RESID_F32>(k, stream);
+    case HM_EPI_RESID_F32:
+      // persistent form: bit-identical, measured NOT faster (all workgroups reach their 512 KB-per-tile epilogues in
+      // lockstep; the one-tile kernel's workgroups drift apart and spread that traffic): opt-in, HM_FP8P_RESID=1
+      if (getenv("HM_FP8P_RESID") != nullptr && fp8p_ok(k) && k.resid_mod == 0 && (k.ldr & 3) == 0 && (k.ldc & 3) == 0)
+        return launch_fp8p<HM_EPI_RESID_F32>(k, stream);
+      return launch_fp8<HM_EPI_RESID_F32>(k, stream);
     case HM_EPI_GELU_MX8:
       if (fp8p_ok(k) && (g.ldc & 7) == 0) return launch_fp8p<HM_EPI_GELU_MX8>(k, stream);
       return launch_fp8<HM_EPI_GELU_MX8>(k, stream);

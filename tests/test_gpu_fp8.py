@@ -100,17 +100,25 @@ def test_gemm_fp8_persistent_kernel_is_bit_identical_to_one_tile_kernel(grid, mo
     x8, xs, w8, ws, _ = _operands(M, N, K, seed=11)
     bias = _u("fb", (N,), 0.5, seed=5)
     a = (x8.to(DEV), xs.to(DEV), w8.to(DEV), ws.to(DEV), bias.to(DEV))
+    resid = _u("fr", (M, N), 1.0, seed=6).to(DEV)
     monkeypatch.setenv("HM_FP8_ONE_TILE", "1")
     ref_store = ops.gemm_fp8(*a, L.HM_EPI_STORE)
     ref8, refs = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
+    ref_res = ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=resid)
     monkeypatch.delenv("HM_FP8_ONE_TILE")
     if grid:
         monkeypatch.setenv("HM_FP8P_GRID", grid)
+    monkeypatch.setenv("HM_FP8P_RESID", "1")               # the persistent residual epilogue is opt-in (not faster), still pinned here
     for _ in range(2):
         out = ops.gemm_fp8(*a, L.HM_EPI_STORE)
         o8, os_ = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
         assert torch.equal(out.view(torch.int16), ref_store.view(torch.int16))
         assert torch.equal(o8, ref8) and torch.equal(os_, refs)
+        # fp32 residual epilogue (proj / fc2): residual rows prefetched into registers by untracked loads, counted waits
+        assert torch.equal(ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=resid), ref_res)
+        x_inplace = resid.clone()                          # the forward updates the residual stream in place
+        ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=x_inplace, out=x_inplace)
+        assert torch.equal(x_inplace, ref_res)
 
 
 def test_gemm_fp8_rejects_bad_arguments():
