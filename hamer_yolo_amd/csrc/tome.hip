@@ -12,6 +12,7 @@
 //                          stable descending rank of the proposals -> unmerged / merged A tokens and their B partners
 //   tome_merge_kernel      size-weighted merge into a new compact residual stream (fp32) and the new sizes
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 #include "hamer_hip_internal.h"
 
@@ -179,6 +180,10 @@ extern "C" int hm_tome_attention(const void* qkv, const float* size, void* out, 
   if (head_dim != TM_HD || tokens <= 0 || tokens > TM_MAXT) return hm_set_error(HM_ERR_ARG, "hm_tome_attention: head_dim 80, 0 < tokens <= 192");
   hipStream_t s = (hipStream_t)stream_;
   HmProfScope prof(HM_K_ATTENTION, 1, B, tokens, heads, s);
+  // the MFMA kernel of the dense path (attention.hip) with a runtime token count; HM_TOME_SCALAR_ATTENTION=1 keeps the
+  // fp32 lane-per-key kernel below (the first implementation: 7x slower, kept as a second opinion for the tests)
+  if ((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0 && getenv("HM_TOME_SCALAR_ATTENTION") == nullptr)
+    return hm_attention_tome_launch(qkv, size, out, B, tokens, heads, scale, dtype, s);
   if (dtype == HM_DTYPE_BF16)
     hipLaunchKernelGGL(tome_attention_kernel<__bf16>, dim3(B * heads), dim3(256), 0, s, (const __bf16*)qkv, size, (__bf16*)out, tokens, heads, scale);
   else if (dtype == HM_DTYPE_F16)
