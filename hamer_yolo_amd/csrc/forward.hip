@@ -2,6 +2,7 @@
 // 1 + 4*depth + 1 MFMA GEMMs, LayerNorms, fused attention, the fp32 decoder head and the fused
 // MANO tail.  Host code only sequences kernels; no allocation, no sync (graph-capturable).
 #include "common.h"
+#include <stdlib.h>
 #include "hamer_hip_internal.h"
 
 int hm_split_head(const float* head, int ldh, float* pose6d, float* betas, float* cam, int B, hipStream_t s);
@@ -64,6 +65,10 @@ Layout make_layout(const hm_hamer_weights& w, int B) {
     L.tmetric = o; o += align256(M * (D / w.heads) * 4);
     L.tindex = o; o += align256(hm_tome_index_bytes(B));
     L.ksplit_proj = L.ksplit_fc2 = 1;
+    // the token count shrinks block by block: late blocks have a few hundred rows, and their N = D GEMMs are split over K
+    // like the few-hands path (pick_split_k per block: <= 8 slabs of <= 2048 rows)
+    const size_t prow = M < 2048 ? M : 2048;
+    L.partials = o; o += align256(8 * prow * D * 4);
   }
   L.total = o;
   return L;
@@ -176,6 +181,20 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
       g.epilogue = epi; g.dtype = dt;
       return hm_gemm(&g, stream);
     };
+    // xcur += X.W^T + bias for Mi rows: one residual GEMM, or -- once merging has left few rows -- K split into slabs that
+    // hm_layernorm_accum adds in a fixed order (its LayerNorm output lands in h and is simply overwritten by the
+    // LayerNorm the block issues next)
+    auto resid_m = [&](int Mi, const void* X, int K, const void* W, const float* bias, float* xcur, const float* lg, const float* lb) {
+      const int ks = getenv("HM_TOME_NO_SPLITK") ? 1 : pick_split_k(Mi, D, K);     // (the env switch: tests compare the two routes)
+      if (ks > 1 && Mi <= 2048) {
+        hm_gemm_args g{};
+        g.X = X; g.W = W; g.C = partials; g.M = Mi; g.N = D; g.K = K; g.ldx = K; g.ldw = K; g.ldc = D;
+        g.epilogue = HM_EPI_F32; g.dtype = dt; g.k_split = ks;
+        HM_TRY(hm_gemm(&g, stream));
+        return hm_layernorm_accum(xcur, partials, ks, bias, lg, lb, h, dt, Mi, D, w->vit_eps, stream);
+      }
+      return gemm_m(Mi, X, K, W, K, D, xcur, D, bias, HM_EPI_RESID_F32, xcur, D, 0);
+    };
     HM_TRY(gemm_m(M, ws + L.patches, kpe, w->patch_w, kpe, D, xc, D, w->patch_b, HM_EPI_RESID_F32, w->pos, D, tokens));
     for (int i = 0; i < w->depth; ++i) {
       const hm_vit_block& b = w->blocks[i];
@@ -183,7 +202,7 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
       HM_TRY(hm_layernorm(xc, b.ln1_g, b.ln1_b, h, dt, Mi, D, w->vit_eps, stream));
       HM_TRY(gemm_m(Mi, h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
       HM_TRY(hm_tome_attention(qkv, szc, att, B, T, w->heads, D / w->heads, scale, dt, stream));
-      HM_TRY(gemm_m(Mi, att, D, b.proj_w, D, D, xc, D, b.proj_b, HM_EPI_RESID_F32, xc, D, 0));
+      HM_TRY(resid_m(Mi, att, D, b.proj_w, b.proj_b, xc, b.ln2_g, b.ln2_b));
       int r = w->tome_r[i] < T / 2 ? w->tome_r[i] : T / 2;          // r = min(r, t // 2) (:42)
       if (r > 0) {
         HM_TRY(hm_tome_merge(qkv, xc, szc, xn, szn, (float*)(ws + L.tmetric), (int*)(ws + L.tindex), B, T, r, w->heads,
@@ -196,7 +215,7 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
       }
       HM_TRY(hm_layernorm(xc, b.ln2_g, b.ln2_b, h, dt, Mi, D, w->vit_eps, stream));
       HM_TRY(gemm_m(Mi, h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0));
-      HM_TRY(gemm_m(Mi, mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, xc, D, b.fc2_b, HM_EPI_RESID_F32, xc, D, 0));
+      HM_TRY(resid_m(Mi, mlp, w->mlp_dim, b.fc2_w, b.fc2_b, xc, b.ln2_g, b.ln2_b));
     }
     HM_TRY(hm_layernorm(xc, w->last_g, w->last_b, tok, dt, B * T, D, w->vit_eps, stream));
     ctx_tokens = T;

@@ -285,6 +285,28 @@ def test_tome_vith_schedule_runs_to_one_token():
     assert float((dense["pose6d"] - a["pose6d"]).abs().max()) > 1e-3
 
 
+def test_tome_late_blocks_split_k_equals_unsplit_route():
+    """Once merging has left <= 1536 rows, proj / fc2 of the ToMe path are split over K (slabs added by hm_layernorm_accum, as
+    in the few-hands path).  With a schedule that stops merging at 15 tokens (so that no near-tie can flip afterwards: 26
+    blocks of 60-row GEMMs follow) the split and the unsplit (HM_TOME_NO_SPLITK=1) routes differ by fp32 summation order only."""
+    cfg = synth.HamerConfig()
+    sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
+    eng = HamerEngine(sd, synth.mano_params(seed=0), cfg, token_merge=[90, 45, 22, 11, 6, 3])
+    assert eng.ctx_tokens == 15
+    img = synth.normalize_crops(synth.crops_u8(4, seed0=0)).cuda()
+    a = {k: v.clone() for k, v in eng.forward(img).items()}
+    os.environ["HM_TOME_NO_SPLITK"] = "1"
+    try:
+        c = eng.forward(img)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["HM_TOME_NO_SPLITK"]
+    d_pose = float((c["pose6d"] - a["pose6d"]).abs().max())
+    d_vert = float((c["pred_vertices"] - a["pred_vertices"]).abs().max())
+    _report("tome_split_k_vs_unsplit", pose6d=d_pose, vertices=d_vert)
+    assert torch.isfinite(a["pred_vertices"]).all() and d_pose < 5e-4 and d_vert < 2e-4       # measured 1.8e-4 / 3e-5
+
+
 def test_persistent_gemm_is_bit_identical_to_one_tile_kernels_at_batch64():
     """gemm_px_kernel (the default for qkv / fc1 / to_kv at B = 64: 720 / 960 / 1152 tiles on 256 persistent workgroups, LDS-DMA
     pipeline across tile boundaries, hand-counted vmcnt) rounds exactly as the one-tile kernels do, so a whole B = 64 forward
