@@ -15,7 +15,7 @@ def _per_hand(value, n: int, like: torch.Tensor) -> torch.Tensor:
 def custom_cam_crop_to_full(cam_bbox, box_center, box_size, img_size, fx, fy, cx, cy, depth_refine=None):
     """cam_bbox (B,3) = (s, tx, ty) on the crop; box_center (B,2), box_size (B,) in frame pixels; intrinsics per hand or
     shared.  With ``depth_refine`` (metres, RootNet) the depth is taken from it and the box scale follows from the depth.
-    ``ty`` is rescaled by fx / fy when the focal lengths differ anywhere in the batch.  Returns (B,3) = (tx, ty, tz)."""
+    ``ty`` is rescaled by fx / fy (a factor of exactly 1 when the focal lengths agree).  Returns (B,3) = (tx, ty, tz)."""
     n = cam_bbox.shape[0]
     f = torch.stack([_per_hand(fx, n, cam_bbox), _per_hand(fy, n, cam_bbox)], dim=1)            # (B, 2)
     pp = torch.stack([_per_hand(cx, n, cam_bbox), _per_hand(cy, n, cam_bbox)], dim=1)
@@ -26,8 +26,10 @@ def custom_cam_crop_to_full(cam_bbox, box_center, box_size, img_size, fx, fy, cx
         tz = _per_hand(depth_refine, n, cam_bbox)
         bs = 2 * f[:, 0] / (tz + 1e-9)
     t_xy = 2 * (box_center[:, :2] - pp) / bs.unsqueeze(1) + cam_bbox[:, 1:3]
-    if not torch.allclose(f[:, 0], f[:, 1]):
-        t_xy = t_xy * torch.stack([torch.ones_like(tz), f[:, 0] / f[:, 1]], dim=1)
+    # ty * fx / fy, unconditionally: with fx == fy the factor is exactly 1.0 and the product exact, and a data-dependent
+    # `if` here would read a device value back -- a host sync in the middle of the folder drivers' pipeline (it was: 175 ms
+    # of a 253 ms pass over 64 frames went to waiting in that test)
+    t_xy = t_xy * torch.stack([torch.ones_like(tz), f[:, 0] / f[:, 1]], dim=1)
     return torch.cat([t_xy, tz.unsqueeze(1)], dim=1)
 
 
