@@ -78,6 +78,9 @@ __device__ __forceinline__ float quad_max(float v) {
   v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
   return v;
 }
+__device__ __forceinline__ float pair_max(float v) {      // max over lanes 2k, 2k+1
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+}
 __device__ __forceinline__ float row8_max(float v) {
   v = quad_max(v);
   return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));

@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8p_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU_MX8 || EPI == HM_EPI_RESID_F32, "qkv / fc1 / proj, fc2 epilogues");
   constexpr int WN = 2, MI = 4, NI = 8, BM = 256, BKB = 128;
   constexpr int TILE_BYTES = 256 * BKB, SCALE_BYTES = 4 * BM, STAGE_BYTES = 2 * TILE_BYTES + SCALE_BYTES;
-  constexpr int NSTORE = EPI == HM_EPI_STORE ? 16 : 32;             // stores per wave and tile (RESID_F32: 32 x 16 B of fp32)
+  constexpr int NSTORE = EPI == HM_EPI_RESID_F32 ? 32 : 16;         // stores per wave and tile (RESID_F32: 32 x 16 B of fp32; MX8: 8 data + 8 scale)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1470,6 +1470,57 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8p_kernel(const KArgs g) {
           float* o = (float*)g.C + (size_t)m * g.ldc + n;
           *(f32x4_t*)o = v0 + r[2 * it];
           *(f32x4_t*)(o + 4) = v1 + r[2 * it + 1];
+        }
+      }
+    } else if constexpr (EPI == HM_EPI_GELU_MX8) {
+      // GELU -> MXFP8 in column groups of 64: a lane holds 16 consecutive columns of a row (half an MX block), the four
+      // lanes of a row 64 bytes of e4m3 -- every data store is 16 B per lane and 64 B per row (the 32-column form stored
+      // 8 B per lane, 32-B row segments, and twice as many instructions).  Staging: 32 rows x 256 B per wave = 8 KB, all
+      // waves inside the consumed stage's X and W parts.  8 data + 8 scale stores per wave.
+      char* wl8 = stg + wave * 8192;
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        const int cw = grp >> 1, half = grp & 1;                 // columns 64 cw .., rows 32 half ..
+#pragma unroll
+        for (int nl = 0; nl < 4; ++nl) {
+          const f32x4_t wsv = *(const f32x4_t*)(cb + 128 + cw * 64 + nl * 16 + 4 * apiece);
+#pragma unroll
+          for (int mm = 0; mm < 2; ++mm) {
+            const int row = mm * 16 + arow;
+            *(f32x4_t*)(wl8 + row * 256 + (((nl * 4 + apiece) ^ (row & 15)) << 4)) = acc[cw * 4 + nl][half * 2 + mm] * wsv;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 16 + row0, sw = row & 15, m = mb + half * 32 + row, n = nb + cw * 64 + 16 * j;
+          f32x4_t v[4];
+          float amax = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v[c] = *(const f32x4_t*)(wl8 + row * 256 + (((4 * j + c) ^ sw) << 4));
+            const f32x4_t bi = *(const f32x4_t*)(cb + cw * 64 + 16 * j + 4 * c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[c][q] = __fadd_rn(v[c][q], bi[q]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c += 2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x2_t gq = gelu_fast2(f32x2_t{v[c][q], v[c + 1][q]});
+              v[c][q] = gq[0]; v[c + 1][q] = gq[1];
+              amax = fmaxf(amax, fmaxf(fabsf(gq[0]), fabsf(gq[1])));
+            }
+          const unsigned sb = mx8_scale_byte(pair_max(amax));    // lanes 2k, 2k+1 of a row hold one 32-column block
+          const float inv = mx8_inv_scale(sb);
+          int4 o8;
+          o8.x = mx8_pack4(v[0][0] * inv, v[0][1] * inv, v[0][2] * inv, v[0][3] * inv);
+          o8.y = mx8_pack4(v[1][0] * inv, v[1][1] * inv, v[1][2] * inv, v[1][3] * inv);
+          o8.z = mx8_pack4(v[2][0] * inv, v[2][1] * inv, v[2][2] * inv, v[2][3] * inv);
+          o8.w = mx8_pack4(v[3][0] * inv, v[3][1] * inv, v[3][2] * inv, v[3][3] * inv);
+          *(int4*)((char*)g.C + (size_t)m * g.ldc + n) = o8;
+          // one scale byte per (row, block): both lanes of the pair issue the store (same byte, same value): an unconditional
+          // instruction, so the store count per wave is a constant
+          g.out_scales[(size_t)(n >> 5) * g.M + m] = (unsigned char)sb;
         }
       }
     } else {
@@ -1806,7 +1857,7 @@ extern "C" int hm_gemm_fp8(const hm_gemm_fp8_args* a, void* stream_) {
         return launch_fp8p<HM_EPI_RESID_F32>(k, stream);
       return launch_fp8<HM_EPI_RESID_F32>(k, stream);
     case HM_EPI_GELU_MX8:
-      if (fp8p_ok(k) && (g.ldc & 7) == 0) return launch_fp8p<HM_EPI_GELU_MX8>(k, stream);
+      if (fp8p_ok(k) && (g.ldc & 15) == 0) return launch_fp8p<HM_EPI_GELU_MX8>(k, stream);
       return launch_fp8<HM_EPI_GELU_MX8>(k, stream);
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: epilogue must be STORE, RESID_F32 or GELU_MX8");
   }
