@@ -263,27 +263,9 @@ def main():
         # configs[3]: this rank's contiguous share of the seeded crop set, resident in HBM, in forwards of B crops
         lo, hi = shard.shard_range(args.crops, rank, world)
         mine = synth.normalize_crops(synth.crops_u8(hi - lo, seed0=lo)).to(dev) if hi > lo else None
-        pieces = [(a, min(a + B, hi - lo)) for a in range(0, hi - lo, B)]
-        packed = torch.zeros(hi - lo, shard.PARAMS_PER_HAND, device=dev)
-        tail_ctx = {}
-
-        def step():
-            for j, (a, b) in enumerate(pieces):
-                c = ctxs[j % nfl]
-                if b - a == B:
-                    eng.forward_on(c, mine[a:b])
-                    res = c.out
-                else:                                       # ragged last forward of the shard: own outputs, same context stream
-                    if "out" not in tail_ctx:
-                        tail_ctx["out"] = eng.alloc_outputs(b - a)
-                    c.stream.wait_stream(torch.cuda.current_stream(dev))
-                    with torch.cuda.stream(c.stream):
-                        res = eng.forward(mine[a:b].contiguous(), tail_ctx["out"], workspace=c.workspace)
-                with torch.cuda.stream(c.stream):
-                    packed[a:b] = shard.pack_mano(res)
-            for c in ctxs:
-                torch.cuda.current_stream(dev).wait_stream(c.stream)
-            return shard.gather_mano(packed, dst=0, n_total=args.crops)    # one collective per job (0.64 MB at 1024 hands)
+        job = shard.ShardJob(eng, mine, args.crops, batch=B, in_flight=nfl)       # the step tests/test_gpu_shard.py checks
+        ctxs = job.ctxs
+        step = job.step
         units_per_step = args.crops
     else:
         # configs[1]: this rank's 64-crop shard (seeds rank*B .. rank*B+B-1), resident in HBM; one forward per step

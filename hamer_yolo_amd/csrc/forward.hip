@@ -185,7 +185,7 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
     // hm_layernorm_accum adds in a fixed order (its LayerNorm output lands in h and is simply overwritten by the
     // LayerNorm the block issues next)
     auto resid_m = [&](int Mi, const void* X, int K, const void* W, const float* bias, float* xcur, const float* lg, const float* lb) {
-      const int ks = getenv("HM_TOME_NO_SPLITK") ? 1 : pick_split_k(Mi, D, K);     // (the env switch: tests compare the two routes)
+      const int ks = hm_option(HM_OPT_TOME_NO_SPLITK) ? 1 : pick_split_k(Mi, D, K);     // (hm_set_option: tests compare the two routes)
       if (ks > 1 && Mi <= 2048) {
         hm_gemm_args g{};
         g.X = X; g.W = W; g.C = partials; g.M = Mi; g.N = D; g.K = K; g.ldx = K; g.ldw = K; g.ldc = D;

@@ -826,6 +826,176 @@ int launch_rs(const KArgs& g, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// gemm_x3_kernel with the fp32 residual fetched INSIDE the K loop (round 3; proj and fc2: 65 of the 130 launches of a step).
+// C = acc + bias + resid moves 2 x 4 bytes per output element through HBM.  Fetched in the epilogue (round 2), the read is
+// paid after the K loop, by every CU at the same moment, while the MFMA pipes idle; during the K loop HBM idles instead (the
+// operands come from L2 / the Infinity Cache).  Here every wave requests its residual tile in the ACCUMULATOR layout -- piece
+// (ni, mi) = 16 rows x 64 B, one global_load_dwordx4 per lane; two pieces of neighbouring ni form whole 128-byte lines --
+// two pieces per K-step during steps 0..15, and adds them into the accumulators two steps later.  The epilogue is then the
+// plain fp32 store epilogue (bias from LDS, no loads).
+//   vmcnt.  Loads and LDS-DMA copies retire in issue order.  Step t issues W(t+1) [4], X(t+2) [4], R(t) [2].  The top of
+//   step t+1 needs W(t+1): everything but the newest 6 (X(t+2), R(t)) -> vmcnt(6), R(t) may stay in flight.  The top of step
+//   t+2 needs W(t+2), issued after R(t): that wait retires R(t) as a side effect, so R(t) has between one and two steps
+//   (1.5-3 us) to arrive before it would stall anything, and is consumed right behind that wait.  The wait statement takes
+//   the two registers as read-write operands: no use or copy of them can be scheduled above it
+//   (tests/test_isa_audit.py checks the emitted ISA).
+//   The 18 steps that issue or consume residual pieces are unrolled (the piece index selects accumulator registers); steps
+//   18.. run in a loop.  Requires whole tiles, K >= 20 x 64, resid_mod == 0, 32-bit residual offsets (launcher: rin_ok).
+template <class T>
+__global__ __launch_bounds__(512, 2) void gemm_x3r_kernel(const KArgs g) {
+  constexpr int WN = 2, MI = 4, NI = 8, NW = 8, BN = 256, BK = 64, ROWB = 128;
+  constexpr int TILE_BYTES = 256 * ROWB;
+  constexpr int XRING = 0, WRING = 3 * TILE_BYTES;
+  constexpr int XI = 4, WI = 4;
+  constexpr int RSTEPS = 16;                            // steps that issue residual pieces: 2 pieces each, 32 in all
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using vec8 = typename T::vec8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = g.N >> 8, tiles_m = g.M >> 8;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, g.group_m, tm, tn);
+  const int m0 = tm << 8, n0 = tn << 8;
+  const int wr = wave / WN, wc = wave % WN;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+
+  const int srow = lane >> 3, swz = (lane & 7) ^ (srow & 7);
+  unsigned xoff[XI], woff[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) xoff[i] = (unsigned)(m0 + wave * XI * 8 + i * 8 + srow) * (unsigned)(g.ldx * 2) + swz * 16;
+#pragma unroll
+  for (int i = 0; i < WI; ++i) woff[i] = (unsigned)(n0 + wave * WI * 8 + i * 8 + srow) * (unsigned)(g.ldw * 2) + swz * 16;
+  auto dma_x = [&](int slot, int kt) {
+    const char* base = X + (size_t)kt * ROWB;
+    char* l = smem + XRING + slot * TILE_BYTES + wave * XI * 1024;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) glds16_hidden_s(base, xoff[i], l + i * 1024);
+  };
+  auto dma_w = [&](int slot, int kt) {
+    const char* base = W + (size_t)kt * ROWB;
+    char* l = smem + WRING + slot * TILE_BYTES + wave * WI * 1024;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) glds16_hidden_s(base, woff[i], l + i * 1024);
+  };
+  // residual piece (ni, mi) of this wave: rows mb + 16 mi + (lane & 15), columns nb + 16 ni + 4 (lane >> 4) .. + 3
+  const int mb = m0 + wr * 16 * MI, nb = n0 + wc * 16 * NI;
+  unsigned roff[MI];                                    // byte offset of the lane's row / column quad for ni = 0
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) roff[mi] = (unsigned)(mb + mi * 16 + (lane & 15)) * (unsigned)(g.ldr * 4) + (unsigned)(nb + 4 * (lane >> 4)) * 4;
+  const char* rbase = (const char*)g.resid;
+
+  f32x4_t acc[NI][MI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a)
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fsw = lane & 7, fch = lane >> 4;
+  auto substep = [&](int xslot, int wslot, int ks) {
+    const char* lx = smem + XRING + xslot * TILE_BYTES;
+    const char* lw = smem + WRING + wslot * TILE_BYTES;
+    const int coff = ((ks * 4 + fch) ^ fsw) * 16;
+    vec8 wf[NI], xf[MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int nk = g.K / BK;                              // launcher: nk >= RSTEPS + 4
+  dma_x(0, 0);
+  dma_w(0, 0);
+  dma_x(1, 1);
+  float bias_reg = 0.f;
+  if (g.bias) bias_reg = g.bias[n0 + (tid & (BN - 1))];  // a plain load: hipcc waits for it at its first use, after the loop
+  if (g.bias) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // X(0), W(0) landed; X(1) and the bias may stay in flight
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+
+  f32x4_t rq[3][2];                                     // residual pieces in flight: issued in step t, consumed in step t + 2
+  // One unrolled step.  T_ = step index (compile time): issues R(T_) when T_ < RSTEPS, consumes R(T_ - 2) when 2 <= T_ < RSTEPS + 2.
+  auto ustep = [&](auto TC) {
+    constexpr int t = decltype(TC)::value;
+    constexpr bool CONSUME = t >= 2 && t < RSTEPS + 2;
+    constexpr bool PREV_ISSUED = t >= 1 && t - 1 < RSTEPS;           // step t - 1 put 2 residual loads behind its copies
+    if constexpr (t >= 1) {
+      if constexpr (CONSUME) {
+        f32x4_t (&r)[2] = rq[(t - 2) % 3];
+        if constexpr (PREV_ISSUED) asm volatile("s_waitcnt vmcnt(6)" : "+v"(r[0]), "+v"(r[1]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(r[0]), "+v"(r[1]) :: "memory");
+        constexpr int p = t - 2, ni0 = 2 * (p / 4), mi = p % 4;
+        acc[ni0][mi] += r[0];                           // (before the barrier: this wave would be waiting for the others anyway)
+        acc[ni0 + 1][mi] += r[1];
+      } else {
+        if constexpr (PREV_ISSUED) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_s_barrier();                      // step t complete in LDS; everyone is done reading step t-1's slots
+    constexpr int xs = t % 3, xs2 = (t + 2) % 3;
+    substep(xs, t & 1, 0);
+    dma_w((t + 1) & 1, t + 1);                         // W first, then X, then the residual pieces: the counted waits rely on this order
+    dma_x(xs2, t + 2);
+    if constexpr (t < RSTEPS) {
+      constexpr int ni0 = 2 * (t / 4), mi = t % 4;
+      f32x4_t (&r)[2] = rq[t % 3];
+      asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:64"
+                   : "=&v"(r[0]), "=&v"(r[1]) : "v"(roff[mi]), "s"(rbase + ni0 * 64) : "memory");
+    }
+    substep(xs, t & 1, 1);
+  };
+#define HM_USTEP(n) ustep(std::integral_constant<int, n>{})
+  HM_USTEP(0); HM_USTEP(1); HM_USTEP(2); HM_USTEP(3); HM_USTEP(4); HM_USTEP(5); HM_USTEP(6); HM_USTEP(7); HM_USTEP(8);
+  HM_USTEP(9); HM_USTEP(10); HM_USTEP(11); HM_USTEP(12); HM_USTEP(13); HM_USTEP(14); HM_USTEP(15); HM_USTEP(16); HM_USTEP(17);
+#undef HM_USTEP
+  static_assert(RSTEPS + 2 == 18 && 18 % 3 == 0, "the loop below starts at step 18 with X slot 0");
+  int xs = 0;
+  for (int kt = RSTEPS + 2; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int xs2 = xs == 0 ? 2 : xs - 1;
+    substep(xs, kt & 1, 0);
+    if (kt + 1 < nk) dma_w((kt + 1) & 1, kt + 1);
+    if (kt + 2 < nk) dma_x(xs2, kt + 2);
+    substep(xs, kt & 1, 1);
+    xs = xs == 2 ? 0 : xs + 1;
+  }
+
+  __builtin_amdgcn_s_barrier();                        // the ring is free: per-column vectors, then epilogue staging
+  constexpr int EPI_BYTES = NW * epi_stage_bytes(MI, NI);
+  float2* rowstat = (float2*)(smem + EPI_BYTES);       // unused by this epilogue
+  float* colvec = (float*)(rowstat + 256);
+  if (tid < BN) colvec[tid] = bias_reg;
+  __builtin_amdgcn_s_barrier();
+  epilogue<T, HM_EPI_F32, MI, NI>(g, acc, mb, nb, lane, smem + wave * epi_stage_bytes(MI, NI),
+                                  rowstat + wr * 16 * MI, colvec + wc * 16 * NI, colvec + BN + wc * 16 * NI, 0);
+}
+
+// what gemm_x3r_kernel requires: whole 256 x 256 tiles, the 18 unrolled steps plus at least two more (so that every copy the
+// unrolled steps issue exists), a plain residual (no row modulus), 32-bit residual offsets, 16-byte residual rows
+bool rin_ok(const KArgs& g) {
+  return g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 20 * 64 && g.resid_mod == 0 && g.resid != nullptr && (g.ldr & 3) == 0 &&
+         (size_t)g.M * g.ldr * 4 < (1ull << 32) && hm_option(HM_OPT_RESID_IN_EPILOGUE) == 0;
+}
+
+template <class T>
+int launch_rin(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 5 * 256 * 128;
+  auto kern = gemm_x3r_kernel<T>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
+  hipLaunchKernelGGL(kern, dim3((g.M >> 8) * (g.N >> 8)), dim3(512), LDS, s, g);
+  return hm_check_launch("hm_gemm");
+}
+
+#ifdef HM_ABLATIONS   // experiments live in the tools-only build (python -m hamer_yolo_amd.build --ablations), not in the product
+// ---------------------------------------------------------------------------------------------------------------
 // EXPERIMENT (variant 28): 256x160 tile with BOTH operands two K-steps ahead.  The 256x256 K loop runs at the latency of
 // its copies: W is requested one step before it is needed because a third 32 KB W slot does not fit beside three X slots
 // (160 KB).  A 256x160 tile (waves 4x2, each 64x80 = 4x5 MFMA tiles) fits three slots of each operand (96 + 60 KB), so
@@ -933,6 +1103,8 @@ int launch_d2(const KArgs& g, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, s, g);
   return hm_check_launch("hm_gemm");
 }
+
+#endif  // HM_ABLATIONS (variant 28)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent form of gemm_x3_kernel for the 16-bit store epilogues (qkv, fc1, to_kv: 3-5 tiles per CU at B = 64).
@@ -1045,15 +1217,17 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   int gs = 0, xs = 0;                                  // global step, its X slot (gs % 3); W slot = gs & 1
   for (int ti = 0; ti < my; ++ti) {
     if (ti > 0) origin(ti, m0, n0);
-    // this wave's 128 bias values, two per lane: requested now, first touched at the top of the tile's last K-step (so the
-    // compiler's wait for them sits where nothing but already-needed copies is outstanding), moved to LDS after the loop
-    float bias_lo = 0.f, bias_hi = 0.f;
-    if (g.bias) {
-      // issued from asm so that hipcc does not track them: a tracked load makes it drain vmcnt to 0 where the value is
-      // first touched (the epilogue's top, with the next tile's copies in flight).  The counted waits of steps >= 1
-      // cover them; nothing reads the two registers before the epilogue (checked in the ISA: tools/isa_vm_trace.py).
+    // this wave's 128 bias values, two per lane, requested now and moved to LDS after the loop.  Issued from asm so that
+    // hipcc does not track them: a tracked load makes it drain vmcnt to 0 where the value is first touched (the epilogue's
+    // top, with the next tile's copies in flight).  Always issued (no bias: any valid address, the values are replaced by
+    // zeros behind the fence), so the counted waits below do not depend on g.bias.  The wait of step kt == 1 retires them
+    // (they are older than the copies that wait is for); the fence statement in front of the epilogue names the two
+    // registers, so nothing can touch them earlier (tests/test_isa_audit.py checks the emitted ISA).
+    float bias_lo, bias_hi;
+    {
+      const float* bsrc = g.bias ? g.bias + n0 + wc * 128 : (const float*)g.W;
       asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:256"
-                   : "=&v"(bias_lo), "=&v"(bias_hi) : "v"(lane * 4), "s"(g.bias + n0 + wc * 128) : "memory");
+                   : "=&v"(bias_lo), "=&v"(bias_hi) : "v"(lane * 4), "s"(bsrc) : "memory");
     }
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -1062,10 +1236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     int xs_last = 0, ws_last = 0;
     for (int kt = 0; kt < nk; ++kt, ++gs) {
       if (gs > 0) {
-        if (kt == 0) {                                 // 16 epilogue stores + X(gs+1) (+ the 2 bias loads) may stay in flight
-          if (g.bias) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        }
+        if (kt == 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");           // 16 epilogue stores + X(gs+1) + the 2 bias loads may stay in flight
         else if (gs + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // X(gs+1)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -1079,12 +1250,16 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
       xs = xs == 2 ? 0 : xs + 1;
     }
     __builtin_amdgcn_s_barrier();                      // the last step's two slots are free: epilogue staging
+    // The bias pair landed long ago (the wait of step kt == 1 retired it; >= 16 copies were issued behind it).  This statement
+    // is its fence: at most 12 operations are in flight here (X(gs+1), W(gs+1), X(gs+2)), so it never stalls, and it names the
+    // two registers as read-write operands -- no use, copy or spill of them can be scheduled above it.
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(bias_lo), "+v"(bias_hi) :: "memory");
 
     // ---- epilogue: 64 x 128 per wave = 4 column groups of 32 x 2 half-strips of 32 rows, each through 4 KB of LDS (all
     // eight waves inside the last step's X slot; the wave's 128 bias values wait in 512 B of the last step's W slot).
     // No vector-memory instruction here but the stores: exactly 16 per wave.
     float* cb = (float*)(smem + WRING + ws_last * TILE_BYTES + wave * 512);
-    cb[lane] = bias_lo; cb[64 + lane] = bias_hi;                       // wave-private: written and read by this wave only
+    cb[lane] = g.bias ? bias_lo : 0.f; cb[64 + lane] = g.bias ? bias_hi : 0.f;   // wave-private: written and read by this wave only
     char* wl = smem + XRING + xs_last * TILE_BYTES + wave * 4096;
     const int arow = lane & 15, apiece = lane >> 4, row0 = lane >> 2, j = lane & 3;
     const int mb = m0 + wr * 64, nb = n0 + wc * 128;
@@ -1129,9 +1304,10 @@ int launch_px(const KArgs& g, hipStream_t s) {
   int cus = hm_device_cu_count();
   if (cus <= 0) cus = 256;
   if (g_px_grid == -2) {
-    const char* e = getenv("HM_PX_GRID");                          // tuning runs: workgroups of the persistent GEMM (default: one per CU)
+    const char* e = getenv("HM_PX_GRID");                          // tuning runs, read ONCE: start-up default of HM_OPT_PX_GRID
     g_px_grid = e ? atoi(e) : -1;
   }
+  if (const int o = hm_option(HM_OPT_PX_GRID)) g_px_grid = o;      // explicit setter (hm_set_option) wins
   // (Leaving 16 of the 256 CUs to the other stream's LayerNorm / attention workgroups -- 240 workgroups: the same number of
   // tile-times for 720 / 960 tiles -- was measured neutral with two batches in flight: 3656-3673 hands/s at 224 / 240 / 248 / 256.)
   int want = g_px_grid > 0 ? g_px_grid : cus;
@@ -1147,6 +1323,7 @@ bool px_ok(const KArgs& g) {
          256ull * g.ldx * 2 < (1ull << 32) && 256ull * g.ldw * 2 < (1ull << 32) && (((uintptr_t)g.C) & 15) == 0;
 }
 
+#ifdef HM_ABLATIONS
 // ---------------------------------------------------------------------------------------------------------------
 // Variant 29: the 256x256x64 tile on FOUR waves (one per SIMD), each owning a 128x128 quadrant = 8x8 MFMA tiles.
 // Per K-step and CU that is 64 ds_read_b128 instead of the 96 of the 8-wave kernels (2/3 of the LDS traffic per flop) and
@@ -1289,6 +1466,8 @@ int launch_w4(const KArgs& g, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, s, g);
   return hm_check_launch("hm_gemm");
 }
+
+#endif  // HM_ABLATIONS (variant 29)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent form of gemm_fp8_kernel (the gemm_px_kernel idea on the fp8 MFMA) for the qkv (bf16 out) and fc1 (GELU ->
@@ -1583,10 +1762,7 @@ int launch_fp8p(const KArgs& g, hipStream_t s) {
   const int tiles = (g.M >> 8) * (g.N >> 8);
   int cus = hm_device_cu_count();
   if (cus <= 0) cus = 256;
-  if (const char* e = getenv("HM_FP8P_GRID")) {         // tests: few workgroups, many tiles each
-    const int v = atoi(e);
-    if (v >= 8) cus = v;
-  }
+  if (const int v = hm_option(HM_OPT_FP8P_GRID)) cus = v;   // tests: few workgroups, many tiles each (hm_set_option; a multiple of 8)
   const int grid = (tiles < cus ? tiles : cus) & ~7;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);
   return hm_check_launch("hm_gemm_fp8");
@@ -1594,7 +1770,7 @@ int launch_fp8p(const KArgs& g, hipStream_t s) {
 
 bool fp8p_ok(const KArgs& g) {
   return g.bias != nullptr && g.M % 256 == 0 && g.N % 256 == 0 && g.K >= 256 && (g.M >> 8) * (g.N >> 8) >= 8 && 256ull * g.ldx < (1ull << 32) &&
-         256ull * g.ldw < (1ull << 32) && 4ull * g.M < (1ull << 32) && getenv("HM_FP8_ONE_TILE") == nullptr;
+         256ull * g.ldw < (1ull << 32) && 4ull * g.M < (1ull << 32) && hm_option(HM_OPT_FP8_ONE_TILE) == 0;
 }
 
 // partial (sum, sum of squares) per 64 columns [P][M][2] -> (mean, rstd) per row [M][2]
@@ -1627,10 +1803,30 @@ int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
 int g_group_m = 8;
 int g_variant = -2;    // -2: read HM_GEMM_VARIANT on first use; -1: per-shape default
 
+// what the 32-bit lane offsets of the asm-issued copies (gemm_x3_kernel and the experiments built like it) require
+bool off32_ok(const KArgs& g) { return (size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32); }
+
 template <class T, int EPI>
 int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
   switch (variant) {
-    case 0: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false>(g, s, "hm_gemm");   // 128x128, 4 waves, 2 stages (64 KB, 2 blocks/CU)
+    // ---- the product's tiles: what pick_variant() can choose
+    case 0: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false>(g, s, "hm_gemm");          // 128x128, 4 waves, 2 stages (64 KB, 2 blocks/CU)
+    case 10: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");  // 256x256, waves 4x2 (64x128 each), 2 stages, s_setprio, loads between the sub-steps
+    case 26:                                                                           // persistent 256x256 (gemm_px_kernel), else as 24
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
+        if (px_ok(g)) return launch_px<T, EPI>(g, s);
+      }
+      [[fallthrough]];
+    case 24:                                                                           // X two K-steps ahead in a 3-slot ring (gemm_x3_kernel)
+      if constexpr (EPI == HM_EPI_RESID_F32) {
+        if (off32_ok(g) && rin_ok(g)) return launch_rin<T>(g, s);   // residual rows fetched inside the K loop (gemm_x3r_kernel)
+      }
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
+        if (off32_ok(g)) return launch_rs<T, EPI>(g, s);
+      }
+      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
+#ifdef HM_ABLATIONS
+    // ---- experiments (correct results, measured and not adopted: DESIGN.md section 4); tools and opt-in tests only
     case 1: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false>(g, s, "hm_gemm");   // 256x128, 8 waves, 3 stages (144 KB)
     case 2: return launch_cfg<T, EPI, 2, 4, 8, 4, 2, false>(g, s, "hm_gemm");   // 256x256, 8 waves, 2 stages (128 KB)
     case 3: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false>(g, s, "hm_gemm");   // 256x128, 8 waves, 2 stages (96 KB)
@@ -1640,11 +1836,31 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 7: return launch_cfg<T, EPI, 2, 4, 8, 4, 3, false, 32>(g, s, "hm_gemm");   // 256x256x32, 8 waves, 3 stages (96 KB)
     case 8: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false>(g, s, "hm_gemm");       // 256x256, waves 4x2 (64x128 each), 2 stages
     case 9: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 1>(g, s, "hm_gemm");   // + s_setprio around the MFMA cluster
-    case 10: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");  // + loads issued between the two sub-steps
     case 11: return launch_cfg<T, EPI, 4, 2, 4, 8, 4, false, 32, 1>(g, s, "hm_gemm");  // 256x256x32, 4 stages, setprio
-#ifdef HM_ABLATIONS   // timing ablations with WRONG results: only in a -DHM_ABLATIONS build (tools/bench_gemm_ab.py), never in the shipped library
-    case 30: if constexpr (EPI == HM_EPI_STORE) return launch_w4<T, EPI, 1>(g, s); else return hm_set_error(HM_ERR_ARG, "ablation"); // w4 without copies
-    case 31: if constexpr (EPI == HM_EPI_STORE) return launch_w4<T, EPI, 2>(g, s); else return hm_set_error(HM_ERR_ARG, "ablation"); // w4 copies only
+    case 12: return launch_cfg<T, EPI, 4, 4, 4, 4, 2, false, 64, 2>(g, s, "hm_gemm");  // 256x256 on SIXTEEN waves of 64x64 (4 per SIMD, <= 128 VGPRs), 2 stages
+    case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
+    case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
+    case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
+    case 25: return launch_cfg<T, EPI, 4, 2, 4, 10, 2, false, 64, 2>(g, s, "hm_gemm"); // 256x320, waves 4x2 (64x160 each), 2 stages (144 KB)
+    case 28:                                                                           // 256x160, both operands two steps ahead
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
+        if (off32_ok(g) && g.K >= 192) return launch_d2<T, EPI>(g, s);
+      }
+      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
+    case 29:                                                                           // 256x256 on four waves of 128x128 (gemm_w4_kernel)
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
+        if (off32_ok(g) && g.K >= 192) return launch_w4<T, EPI>(g, s);
+      }
+      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
+    // ---- timing ablations with WRONG results (tools/bench_gemm_ab.py only).  The w4 forms carry the guards of case 29:
+    // gemm_w4_kernel's prologue issues K-steps 0..2 unconditionally and its lane offsets are 32-bit.
+    case 30: case 31:
+      if constexpr (EPI == HM_EPI_STORE) {
+        if (!off32_ok(g) || g.K < 192) return hm_set_error(HM_ERR_ARG, "hm_gemm: ablations 30 / 31 need K >= 192 and operands below 4 GB");
+        return variant == 30 ? launch_w4<T, EPI, 1>(g, s) : launch_w4<T, EPI, 2>(g, s);     // w4 without copies / copies only
+      } else {
+        return hm_set_error(HM_ERR_ARG, "hm_gemm: ablations 30 / 31 exist for the store epilogue only");
+      }
     case 16: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 94>(g, s, "hm_gemm"); // everything, but no wave waits for its copies
     case 17: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 95>(g, s, "hm_gemm"); // ... and no barrier
     case 14: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 92>(g, s, "hm_gemm"); // LDS-DMA + waits + barriers only
@@ -1652,44 +1868,15 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // no epilogue
     case 18: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 97>(g, s, "hm_gemm"); // every tile loads operand panel 0 (pure L2 hits)
 #endif
-    case 12: return launch_cfg<T, EPI, 4, 4, 4, 4, 2, false, 64, 2>(g, s, "hm_gemm");  // 256x256 on SIXTEEN waves of 64x64 (4 per SIMD, <= 128 VGPRs), 2 stages
-    case 21: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 2 stages (48 KB): 2 blocks/CU
-    case 22: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false, 32, 1>(g, s, "hm_gemm");  // 256x128x32, 8 waves, 3 stages (72 KB): 2 blocks/CU
-    case 23: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false, 32, 1>(g, s, "hm_gemm");  // 128x128x32, 4 waves, 2 stages (32 KB): 4 blocks/CU
-    case 25: return launch_cfg<T, EPI, 4, 2, 4, 10, 2, false, 64, 2>(g, s, "hm_gemm"); // 256x320, waves 4x2 (64x160 each), 2 stages (144 KB)
-    case 28:                                                                           // EXPERIMENT: 256x160, both operands two steps ahead
-      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
-        if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_d2<T, EPI>(g, s);
-      }
-      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
-    case 29:                                                                           // 256x256 on four waves of 128x128 (gemm_w4_kernel)
-      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
-        if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32) && g.K >= 192) return launch_w4<T, EPI>(g, s);
-      }
-      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
-    case 26:                                                                           // persistent 256x256 (gemm_px_kernel), else as 24
-      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
-        if (px_ok(g)) return launch_px<T, EPI>(g, s);
-      }
-      [[fallthrough]];
-    case 24:                                                                           // X two K-steps ahead in a 3-slot ring (gemm_x3_kernel)
-      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
-        if ((size_t)g.M * g.ldx * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) return launch_rs<T, EPI>(g, s);   // 32-bit lane offsets
-      }
-      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
   }
 }
 
-// The deferred-LayerNorm epilogues exist for the production tiles only (0, 8, 9, 10).
+// The deferred-LayerNorm epilogues exist for the two one-tile production tiles (0, 10).
 template <class T, int EPI>
 int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
-  switch (variant) {
-    case 0: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false>(g, s, "hm_gemm");
-    case 8: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false>(g, s, "hm_gemm");
-    case 9: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 1>(g, s, "hm_gemm");
-    default: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
-  }
+  if (variant == 0) return launch_cfg<T, EPI, 2, 2, 4, 4, 2, false>(g, s, "hm_gemm");
+  return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
 }
 
 // Default tile choice (measured on MI355X, interleaved A/B on the ViT-H shapes, random data): the 256x256 tile halves
@@ -1697,11 +1884,11 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 // wins by 15 % at M = 12288 -- as long as its tiles fill the CUs; small and mid-sized problems keep the 128x128 tile
 // (less padding and round waste, 2 workgroups per CU).
 bool variant_ok(int v) {
-  if (v == -1) return true;
+  if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 14 && v <= 18) || v == 20 || v == 30 || v == 31) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 28 && v <= 31)) return true;
 #endif
-  return (v >= 0 && v <= 12) || (v >= 21 && v <= 26) || v == 28 || v == 29;
+  return false;
 }
 
 int pick_variant(const KArgs& g) {
@@ -1778,7 +1965,7 @@ extern "C" int hm_gemm_set_group_m(int gm) {
 }
 
 extern "C" int hm_gemm_set_variant(int v) {
-  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a tile variant 0..11, 21..26, 28");
+  if (!variant_ok(v)) return hm_set_error(HM_ERR_ARG, "hm_gemm_set_variant: -1 (default) or a shipped tile variant: 0, 10, 24, 26 (experiments and ablations: libhamer_hip_abl.so)");
   g_variant = v;
   return HM_OK;
 }
@@ -1852,8 +2039,8 @@ extern "C" int hm_gemm_fp8(const hm_gemm_fp8_args* a, void* stream_) {
       return launch_fp8<HM_EPI_STORE>(k, stream);
     case HM_EPI_RESID_F32:
       // persistent form: bit-identical, measured NOT faster (all workgroups reach their 512 KB-per-tile epilogues in
-      // lockstep; the one-tile kernel's workgroups drift apart and spread that traffic): opt-in, HM_FP8P_RESID=1
-      if (getenv("HM_FP8P_RESID") != nullptr && fp8p_ok(k) && k.resid_mod == 0 && (k.ldr & 3) == 0 && (k.ldc & 3) == 0)
+      // lockstep; the one-tile kernel's workgroups drift apart and spread that traffic): opt-in, hm_set_option(HM_OPT_FP8P_RESID, 1)
+      if (hm_option(HM_OPT_FP8P_RESID) != 0 && fp8p_ok(k) && k.resid_mod == 0 && (k.ldr & 3) == 0 && (k.ldc & 3) == 0)
         return launch_fp8p<HM_EPI_RESID_F32>(k, stream);
       return launch_fp8<HM_EPI_RESID_F32>(k, stream);
     case HM_EPI_GELU_MX8:

@@ -32,6 +32,7 @@ struct HmLdsOnce {
   }
 };
 int hm_device_cu_count(void);
+int hm_option(int key);               // status.hip: value of an HM_OPT_* switch (0 when never set)
 // attention.hip: the MFMA attention kernel with a runtime token count and proportional attention (used by hm_tome_attention)
 int hm_attention_tome_launch(const void* qkv, const float* size, void* out, int B, int tokens, int heads, float scale, int dtype,
                              hipStream_t s);   // multiProcessorCount of the current device (cached per device), <= 0 on error

@@ -31,5 +31,22 @@ int hm_device_cu_count(void) {
   return n;
 }
 
+// Test / tuning switches (all default 0): plain ints behind explicit setters (relaxed atomics: a setter racing a launch on another host thread
+// changes which kernel that launch takes, never its result).
+#include <atomic>
+static std::atomic<int> g_opts[HM_OPT_COUNT];
+int hm_option(int key) {
+  return (key >= 0 && key < HM_OPT_COUNT) ? g_opts[key].load(std::memory_order_relaxed) : 0;
+}
+extern "C" int hm_get_option(int key) { return hm_option(key); }
+extern "C" int hm_set_option(int key, int value) {
+  if (key < 0 || key >= HM_OPT_COUNT) return hm_set_error(HM_ERR_ARG, "hm_set_option: unknown key");
+  if (value < 0) return hm_set_error(HM_ERR_ARG, "hm_set_option: value must be >= 0");
+  if ((key == HM_OPT_PX_GRID || key == HM_OPT_FP8P_GRID) && value != 0 && (value < 8 || value % 8 != 0))
+    return hm_set_error(HM_ERR_ARG, "hm_set_option: a persistent grid is 0 (default) or a multiple of the 8 XCDs");
+  g_opts[key].store(value, std::memory_order_relaxed);
+  return HM_OK;
+}
+
 extern "C" int hm_version(void) { return HM_VERSION; }
 extern "C" const char* hm_last_error_string(void) { return g_err; }

@@ -182,7 +182,7 @@ extern "C" int hm_tome_attention(const void* qkv, const float* size, void* out, 
   HmProfScope prof(HM_K_ATTENTION, 1, B, tokens, heads, s);
   // the MFMA kernel of the dense path (attention.hip) with a runtime token count; HM_TOME_SCALAR_ATTENTION=1 keeps the
   // fp32 lane-per-key kernel below (the first implementation: 7x slower, kept as a second opinion for the tests)
-  if ((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0 && getenv("HM_TOME_SCALAR_ATTENTION") == nullptr)
+  if ((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0 && hm_option(HM_OPT_TOME_SCALAR_ATTENTION) == 0)
     return hm_attention_tome_launch(qkv, size, out, B, tokens, heads, scale, dtype, s);
   if (dtype == HM_DTYPE_BF16)
     hipLaunchKernelGGL(tome_attention_kernel<__bf16>, dim3(B * heads), dim3(256), 0, s, (const __bf16*)qkv, size, (__bf16*)out, tokens, heads, scale);

@@ -15,6 +15,9 @@ LIB_PATH = os.path.join(HERE, "libhamer_hip.so")
 HM_DTYPE_BF16, HM_DTYPE_F16, HM_OUT_F32 = 0, 1, 2
 HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 3, 4
 HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU, HM_EPI_GELU_MX8 = 5, 6, 7, 8
+HM_VERSION = 300      # include/hamer_hip.h: load() refuses a library built from another header
+(HM_OPT_PX_GRID, HM_OPT_FP8P_GRID, HM_OPT_FP8_ONE_TILE, HM_OPT_FP8P_RESID, HM_OPT_TOME_NO_SPLITK,
+ HM_OPT_TOME_SCALAR_ATTENTION, HM_OPT_RESID_IN_EPILOGUE) = range(7)
 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
@@ -22,7 +25,7 @@ EXPORTS = [
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
-    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge",
+    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -160,6 +163,8 @@ def load() -> C.CDLL:
     lib.hm_tome_merge.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.hm_gemm_set_variant.argtypes = [i]
     lib.hm_gemm_set_group_m.argtypes = [i]
+    lib.hm_set_option.argtypes = [i, i]
+    lib.hm_get_option.argtypes = [i]
     lib.hm_prof_begin.argtypes = [i]
     lib.hm_prof_collect.argtypes = [C.POINTER(ProfRecord), i]
     lib.hm_prof_end.argtypes = []
@@ -169,8 +174,28 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes", "hm_nms_workspace_bytes", "hm_tome_index_bytes"):
             fn.restype = i
+    if lib.hm_version() != HM_VERSION:
+        raise HipLibraryError(f"{LIB_PATH} reports HM_VERSION {lib.hm_version()}, this binding is written for {HM_VERSION}: "
+                              "rebuild it (python -m hamer_yolo_amd.build --force)")
     _lib = lib
     return lib
+
+
+class option:
+    """Context manager over hm_set_option: `with L.option(L.HM_OPT_FP8_ONE_TILE, 1): ...` (tests and tuning tools; the
+    launch paths read these switches, never the environment)."""
+
+    def __init__(self, key: int, value: int):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.old = load().hm_get_option(self.key)
+        check(load().hm_set_option(self.key, self.value), "hm_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        load().hm_set_option(self.key, self.old)
+        return False
 
 
 def check(rc: int, what: str = "") -> None:

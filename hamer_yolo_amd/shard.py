@@ -101,3 +101,40 @@ def gather_mano(packed: torch.Tensor, dst: int = 0, n_total: Optional[int] = Non
     full = torch.empty(world * per, packed.shape[1], dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(full, padded.contiguous())
     return full[:n_total] if rank == dst else None         # shards are contiguous and only trailing ranks are short
+
+
+class ShardJob:
+    """BASELINE configs[3] on one rank: this rank's contiguous share of an n_total-crop job, resident in HBM, run as forwards
+    of `batch` crops on alternating in-flight contexts (a ragged last forward gets its own outputs on the same context's
+    stream and workspace), per-hand MANO parameters packed into one [n_mine][157] buffer, ONE gather per job.  bench.py
+    (--workload shard1024) and tests/test_gpu_shard.py run the same step() -- the reference's counterpart is the serial
+    one-hand loop at hamer/infer.py:1268-1274."""
+
+    def __init__(self, eng, crops: Optional[torch.Tensor], n_total: int, batch: int = 64, in_flight: int = 2):
+        import torch as _t
+        self.eng, self.n_total, self.batch = eng, n_total, batch
+        self.crops = crops                                        # (n_mine, 3, 256, 256) f32 on the device, or None when this rank holds nothing
+        n = 0 if crops is None else crops.shape[0]
+        self.ctxs = eng.contexts(batch, in_flight)
+        self.pieces = [(a, min(a + batch, n)) for a in range(0, n, batch)]
+        self.packed = _t.zeros(n, PARAMS_PER_HAND, device=eng.device)
+        self._tail_out = None
+
+    def step(self) -> Optional[torch.Tensor]:
+        eng, dev, B = self.eng, self.eng.device, self.batch
+        for j, (a, b) in enumerate(self.pieces):
+            c = self.ctxs[j % len(self.ctxs)]
+            if b - a == B:
+                eng.forward_on(c, self.crops[a:b])
+                res = c.out
+            else:                                                  # ragged last forward of the shard
+                if self._tail_out is None:
+                    self._tail_out = eng.alloc_outputs(b - a)
+                c.stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(c.stream):
+                    res = eng.forward(self.crops[a:b].contiguous(), self._tail_out, workspace=c.workspace)
+            with torch.cuda.stream(c.stream):
+                self.packed[a:b] = pack_mano(res)
+        for c in self.ctxs:
+            torch.cuda.current_stream(dev).wait_stream(c.stream)
+        return gather_mano(self.packed, dst=0, n_total=self.n_total)     # one collective per job (0.64 MB at 1024 hands)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HM_VERSION 100
+#define HM_VERSION 300   /* round 3: hm_set_option, hm_hamer_weights.tome_r, hm_nms_workspace_bytes(n, cap) -- lib.load() checks it */
 
 enum { HM_DTYPE_BF16 = 0, HM_DTYPE_F16 = 1 };
 
@@ -75,13 +75,28 @@ typedef struct hm_gemm_args {
 int hm_gemm(const hm_gemm_args* args, void* stream);
 /* HM_EPI_RESID_LN partials [D/64][M][2] -> row_stats [M][2] = (mean, 1/sqrt(var + eps)) for HM_EPI_LN_*. */
 int hm_ln_finalize(const float* partials, float* row_stats, int M, int D, float eps, void* stream);
-/* Tuning hook: pin the GEMM tile configuration (see launch_gemm in gemm.hip; 14, 15, 18, 20 are timing ablations that
- * compute wrong results); -1 restores the default
+/* Tuning hook: pin the GEMM tile configuration (see launch_gemm in gemm.hip: 0 = 128x128, 10 = 256x256 two-stage,
+ * 24 = 256x256 with X two K-steps ahead, 26 = persistent; the experimental tiles and the wrong-result timing ablations
+ * exist only in the -DHM_ABLATIONS build, libhamer_hip_abl.so); -1 restores the default
  * (also settable through the HM_GEMM_VARIANT environment variable).  Results do not depend on it
  * beyond fp32 summation order. */
 int hm_gemm_set_variant(int variant);
 /* Tuning hook: M-tiles per group in the XCD-aware tile walk (default 8). */
 int hm_gemm_set_group_m(int group_m);
+/* Process-wide test / tuning switches.  Launch paths read these, never the environment (HM_GEMM_VARIANT and HM_PX_GRID are
+ * read ONCE, on first use, as start-up defaults for tuning runs).  Returns 0, or HM_ERR_ARG for an unknown key / bad value. */
+enum {
+  HM_OPT_PX_GRID = 0,               /* workgroups of the persistent 16-bit GEMM (0 = one per CU)                        */
+  HM_OPT_FP8P_GRID = 1,             /* workgroups of the persistent fp8 GEMM (0 = one per CU; tests: few, many tiles each) */
+  HM_OPT_FP8_ONE_TILE = 2,          /* 1: hm_gemm_fp8 always takes the one-tile kernel (tests compare the two)           */
+  HM_OPT_FP8P_RESID = 3,            /* 1: persistent fp32-residual fp8 epilogue (bit-identical, measured not faster)     */
+  HM_OPT_TOME_NO_SPLITK = 4,        /* 1: token-merging forward never splits proj / fc2 over K (tests compare the routes) */
+  HM_OPT_TOME_SCALAR_ATTENTION = 5, /* 1: hm_tome_attention takes the fp32 lane-per-key kernel                           */
+  HM_OPT_RESID_IN_EPILOGUE = 6,     /* 1: the fp32-residual GEMM fetches its residual rows in the epilogue (round-2 form) */
+  HM_OPT_COUNT = 7
+};
+int hm_set_option(int key, int value);
+int hm_get_option(int key);
 
 /* The fp8 flavour of hm_gemm for BASELINE configs[4] ("fp8 ViT-H weights on CDNA4 fp8 MFMA"): C = epilogue(X . W^T) on
  * v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 MFMA rate, half the operand bytes).

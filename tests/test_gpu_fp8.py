@@ -91,34 +91,32 @@ def test_layernorm_mx8(D):
     assert ((d_k - y).abs() <= blockmax * 2.0 ** -4 + 1e-6).float().mean().item() > 0.999
 
 
-@pytest.mark.parametrize("grid", [None, "8", "40"])
-def test_gemm_fp8_persistent_kernel_is_bit_identical_to_one_tile_kernel(grid, monkeypatch):
+@pytest.mark.parametrize("grid", [0, 8, 40])
+def test_gemm_fp8_persistent_kernel_is_bit_identical_to_one_tile_kernel(grid):
     """qkv / fc1 shapes of whole 256 x 256 tiles run in the persistent kernel (several tiles per workgroup, the next tile's
     first K-step in flight under the epilogue, hand-counted waits).  Same MFMA order, same epilogue arithmetic: the bytes
-    must equal the one-tile kernel's, for one tile per workgroup (default grid) and for many (HM_FP8P_GRID)."""
+    must equal the one-tile kernel's, for one tile per workgroup (default grid) and for many (HM_OPT_FP8P_GRID)."""
     M, N, K = 2304, 3840, 1280                       # 9 x 15 tiles
     x8, xs, w8, ws, _ = _operands(M, N, K, seed=11)
     bias = _u("fb", (N,), 0.5, seed=5)
     a = (x8.to(DEV), xs.to(DEV), w8.to(DEV), ws.to(DEV), bias.to(DEV))
     resid = _u("fr", (M, N), 1.0, seed=6).to(DEV)
-    monkeypatch.setenv("HM_FP8_ONE_TILE", "1")
-    ref_store = ops.gemm_fp8(*a, L.HM_EPI_STORE)
-    ref8, refs = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
-    ref_res = ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=resid)
-    monkeypatch.delenv("HM_FP8_ONE_TILE")
-    if grid:
-        monkeypatch.setenv("HM_FP8P_GRID", grid)
-    monkeypatch.setenv("HM_FP8P_RESID", "1")               # the persistent residual epilogue is opt-in (not faster), still pinned here
-    for _ in range(2):
-        out = ops.gemm_fp8(*a, L.HM_EPI_STORE)
-        o8, os_ = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
-        assert torch.equal(out.view(torch.int16), ref_store.view(torch.int16))
-        assert torch.equal(o8, ref8) and torch.equal(os_, refs)
-        # fp32 residual epilogue (proj / fc2): residual rows prefetched into registers by untracked loads, counted waits
-        assert torch.equal(ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=resid), ref_res)
-        x_inplace = resid.clone()                          # the forward updates the residual stream in place
-        ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=x_inplace, out=x_inplace)
-        assert torch.equal(x_inplace, ref_res)
+    with L.option(L.HM_OPT_FP8_ONE_TILE, 1):
+        ref_store = ops.gemm_fp8(*a, L.HM_EPI_STORE)
+        ref8, refs = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
+        ref_res = ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=resid)
+    # the persistent residual epilogue is opt-in (not faster), still pinned here
+    with L.option(L.HM_OPT_FP8P_GRID, grid), L.option(L.HM_OPT_FP8P_RESID, 1):
+        for _ in range(2):
+            out = ops.gemm_fp8(*a, L.HM_EPI_STORE)
+            o8, os_ = ops.gemm_fp8(*a, L.HM_EPI_GELU_MX8)
+            assert torch.equal(out.view(torch.int16), ref_store.view(torch.int16))
+            assert torch.equal(o8, ref8) and torch.equal(os_, refs)
+            # fp32 residual epilogue (proj / fc2): residual rows prefetched into registers by untracked loads, counted waits
+            assert torch.equal(ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=resid), ref_res)
+            x_inplace = resid.clone()                          # the forward updates the residual stream in place
+            ops.gemm_fp8(*a, L.HM_EPI_RESID_F32, resid=x_inplace, out=x_inplace)
+            assert torch.equal(x_inplace, ref_res)
 
 
 def test_gemm_fp8_rejects_bad_arguments():

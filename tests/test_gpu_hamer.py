@@ -133,7 +133,7 @@ def test_batch64_vs_fp32_oracle_at_production_tile():
 
 def test_batch64_is_batch_invariant():
     """BASELINE config 2 size (B=64): per-crop results do not depend on the batch they ride in -- repeated crops give
-    identical rows, a batch of 16 (other GEMM tile shapes, same summation order) gives the same numbers, a batch of 8 (split-K
+    identical rows, a batch of 16 (other GEMM tile shapes, same K order) gives the same numbers to fp32 rounding, a batch of 8 (split-K
     path: other summation order, other rounding flips) stays far inside the 1e-3 parity bar -- and the output is finite."""
     cfg = synth.HamerConfig()
     sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
@@ -149,7 +149,9 @@ def test_batch64_is_batch_invariant():
         a, b = o16[k], o64[k]
         assert torch.isfinite(b).all()
         assert torch.equal(b[:16], b[48:64]), k
-        np.testing.assert_allclose(b[:16].cpu().numpy(), a.cpu().numpy(), atol=1e-6, rtol=0)
+        # (round 3: at B = 64 the residual rows are added inside the K loop of proj / fc2, at B = 16 behind it -- one fp32 add
+        # per element changes position, 64 times over the backbone)
+        np.testing.assert_allclose(b[:16].cpu().numpy(), a.cpu().numpy(), atol=2e-5, rtol=0)
         np.testing.assert_allclose(o8[k].cpu().numpy(), b[:8].cpu().numpy(), atol=5e-4, rtol=0)
     r = o64["rotmats"]
     eye = torch.eye(3, device="cuda").expand_as(r)
@@ -288,19 +290,16 @@ def test_tome_vith_schedule_runs_to_one_token():
 def test_tome_late_blocks_split_k_equals_unsplit_route():
     """Once merging has left <= 1536 rows, proj / fc2 of the ToMe path are split over K (slabs added by hm_layernorm_accum, as
     in the few-hands path).  With a schedule that stops merging at 15 tokens (so that no near-tie can flip afterwards: 26
-    blocks of 60-row GEMMs follow) the split and the unsplit (HM_TOME_NO_SPLITK=1) routes differ by fp32 summation order only."""
+    blocks of 60-row GEMMs follow) the split and the unsplit (HM_OPT_TOME_NO_SPLITK) routes differ by fp32 summation order only."""
     cfg = synth.HamerConfig()
     sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
     eng = HamerEngine(sd, synth.mano_params(seed=0), cfg, token_merge=[90, 45, 22, 11, 6, 3])
     assert eng.ctx_tokens == 15
     img = synth.normalize_crops(synth.crops_u8(4, seed0=0)).cuda()
     a = {k: v.clone() for k, v in eng.forward(img).items()}
-    os.environ["HM_TOME_NO_SPLITK"] = "1"
-    try:
+    with L.option(L.HM_OPT_TOME_NO_SPLITK, 1):
         c = eng.forward(img)
         torch.cuda.synchronize()
-    finally:
-        del os.environ["HM_TOME_NO_SPLITK"]
     d_pose = float((c["pose6d"] - a["pose6d"]).abs().max())
     d_vert = float((c["pred_vertices"] - a["pred_vertices"]).abs().max())
     _report("tome_split_k_vs_unsplit", pose6d=d_pose, vertices=d_vert)

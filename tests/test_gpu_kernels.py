@@ -43,10 +43,7 @@ def test_gemm_exact_integers_asymmetric():
         assert torch.equal(out.cpu(), ref)
 
 
-@pytest.mark.parametrize("variant", list(range(13)))
-def test_gemm_tile_variants_exact(variant):
-    """Every tile / pipeline configuration of gemm.hip on exact-integer data (bit-exact whatever the
-    summation order), ragged M and N, several K-tile counts (ring prologue / steady state / tail)."""
+def _tile_variant_exact(variant):
     lib = L.load()
     try:
         L.check(lib.hm_gemm_set_variant(variant))
@@ -59,6 +56,42 @@ def test_gemm_tile_variants_exact(variant):
             assert torch.equal(out.cpu(), ref), (variant, M, N, K)
     finally:
         lib.hm_gemm_set_variant(-1)
+
+
+@pytest.mark.parametrize("variant", [0, 10, 24, 26])
+def test_gemm_tile_variants_exact(variant):
+    """Every tile / pipeline configuration the product library ships (what pick_variant can choose) on exact-integer data
+    (bit-exact whatever the summation order), ragged M and N, several K-tile counts (ring prologue / steady state / tail)."""
+    _tile_variant_exact(variant)
+
+
+def test_gemm_set_variant_accepts_shipped_tiles_only():
+    """The experimental tiles (1-9, 11, 12, 21-23, 25, 28, 29) and the wrong-result ablations live in libhamer_hip_abl.so
+    (python -m hamer_yolo_amd.build --ablations); the product refuses them instead of silently running something else."""
+    lib = L.load()
+    for v in (1, 8, 9, 12, 14, 17, 21, 23, 25, 28, 29, 30, 31, 99):
+        assert lib.hm_gemm_set_variant(v) != 0, v
+    for v in (0, 10, 24, 26, -1):
+        assert lib.hm_gemm_set_variant(v) == 0, v
+
+
+@pytest.fixture
+def experiments_lib(monkeypatch):
+    """libhamer_hip_abl.so (experimental tiles; opt-in: HM_TEST_EXPERIMENTS=1 and the library built) in place of the product
+    library for one test."""
+    import os
+    path = L.LIB_PATH.replace(".so", "_abl.so")
+    if os.environ.get("HM_TEST_EXPERIMENTS") != "1" or not os.path.exists(path):
+        pytest.skip("experimental GEMM tiles: build with `python -m hamer_yolo_amd.build --ablations` and set HM_TEST_EXPERIMENTS=1")
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", path)
+    yield L.load()
+    L._lib = None                                     # (monkeypatch restores LIB_PATH; the next load() opens the product library again)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 21, 22, 23])
+def test_gemm_experimental_tiles_exact(variant, experiments_lib):
+    _tile_variant_exact(variant)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
@@ -126,7 +159,7 @@ def test_gemm_persistent_kernel_exact(dt):
 
 @pytest.mark.parametrize("variant", [25, 28, 29])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_gemm_256x320_tile_exact(dt, variant):
+def test_gemm_256x320_tile_exact(dt, variant, experiments_lib):
     """Variant 25 (256x320 tile) and variant 28 (256x160 tile, both operands two K-steps ahead in three-slot rings, hand-counted
     vmcnt with a wave-dependent copy count) on exact-integer data, ragged and whole shapes, 1 / 2 / 3 / many K-steps, every
     epilogue family they can be given: 16-bit store, fp32 out, fp32 residual; repeated launches as a race screen."""
@@ -183,7 +216,42 @@ def test_gemm_epilogues(M, N, K, dt):
         np.testing.assert_allclose(o.numpy(), ref.numpy(), atol=1e-4 * math.sqrt(K) + 2e-3, rtol=2 * ulp)
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 8, 9, 10])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_inloop_residual_exact(dt):
+    """gemm_x3r_kernel (round 3: the fp32 residual rows of proj / fc2 are requested inside the K loop, two accumulator-layout
+    pieces per K-step by loads hipcc does not track, added into the accumulators two steps later behind a counted wait that
+    names the registers) on exact-integer data: the minimum K (20 steps: 18 unrolled + 2), one more, and fc2's 80; whole
+    tiles only (others fall back to the epilogue form); the residual aliasing the output as in the forward (x += ...);
+    repeated launches as a race screen; and against the round-2 epilogue form (HM_OPT_RESID_IN_EPILOGUE) on random data,
+    where the two differ by the position of one fp32 add."""
+    lib = L.load()
+    for (M, N, K) in ((512, 1280, 1280), (768, 256, 1344), (256, 512, 5120), (2304, 1280, 1280)):
+        x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+        w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+        bias = (torch.arange(N) % 9 - 4).float()
+        resid = ((torch.arange(M * N).reshape(M, N) * 3 + torch.arange(N)[None, :] * 7) % 1021 - 510).float()
+        xd, wd, bd, rd = x.to(DEV, dt), w.to(DEV, dt), bias.to(DEV), resid.to(DEV)
+        ref = x @ w.t() + bias + resid
+        for _ in range(3):
+            assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd).cpu(), ref), (M, N, K)
+        inplace = rd.clone()
+        ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=inplace, out=inplace)
+        assert torch.equal(inplace.cpu(), ref), (M, N, K)
+        assert torch.equal(ops.gemm(xd, wd, None, L.HM_EPI_RESID_F32, resid=rd).cpu(), ref - bias), (M, N, K)     # no bias
+        with L.option(L.HM_OPT_RESID_IN_EPILOGUE, 1):
+            assert torch.equal(ops.gemm(xd, wd, bd, L.HM_EPI_RESID_F32, resid=rd).cpu(), ref), (M, N, K)
+    M, N, K = 1024, 1280, 5120
+    a, wt = _u("ra", (M, K), 1.0, seed=1).to(DEV, dt), _u("rw", (N, K), 0.05, seed=2).to(DEV, dt)
+    bb, rr = _u("rb", (N,), 0.5, seed=3).to(DEV), _u("rr", (M, N), 2.0, seed=4).to(DEV)
+    new = ops.gemm(a, wt, bb, L.HM_EPI_RESID_F32, resid=rr)
+    with L.option(L.HM_OPT_RESID_IN_EPILOGUE, 1):
+        old = ops.gemm(a, wt, bb, L.HM_EPI_RESID_F32, resid=rr)
+    ref64 = (a.double() @ wt.double().t() + bb.double() + rr.double()).cpu()
+    assert float((new - old).abs().max()) < 2e-5                         # one fp32 add moved: a few ulps of |x| <= ~10
+    assert float((new.cpu().double() - ref64).abs().max()) <= float((old.cpu().double() - ref64).abs().max()) * 1.5 + 1e-6
+
+
+@pytest.mark.parametrize("variant", [-1, 0, 10])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_gemm_deferred_layernorm(variant, dt):
     """HM_EPI_RESID_LN -> HM_EPI_LN_STORE / HM_EPI_LN_GELU == residual add, nn.LayerNorm, nn.Linear (vit.py:148-151):

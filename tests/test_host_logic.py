@@ -28,7 +28,22 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/hamer_hip.h but not exported"
-    assert lib.hm_version() == 100
+    assert lib.hm_version() == L.HM_VERSION == int(re.search(r"#define HM_VERSION (\d+)", hdr).group(1))
+
+
+def test_options_are_explicit_setters_not_environment_reads(monkeypatch):
+    """launch paths must not call getenv (a stray variable or a test's setenv would change which kernel runs).
+    The switches live behind hm_set_option / hm_get_option; only the two start-up tuning defaults are read from the
+    environment, once."""
+    lib = L.load()
+    for key in range(7):
+        assert lib.hm_get_option(key) == 0
+    assert lib.hm_set_option(99, 1) != 0 and lib.hm_set_option(L.HM_OPT_FP8P_GRID, 12) != 0 and lib.hm_set_option(0, -1) != 0
+    with L.option(L.HM_OPT_FP8P_GRID, 40):
+        assert lib.hm_get_option(L.HM_OPT_FP8P_GRID) == 40
+    assert lib.hm_get_option(L.HM_OPT_FP8P_GRID) == 0
+    src = "".join(open(os.path.join(ROOT, "hamer_yolo_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "hamer_yolo_amd", "csrc")))
+    assert sorted(set(re.findall(r'getenv\("(\w+)"\)', src))) == ["HM_GEMM_VARIANT", "HM_PX_GRID"]
 
 
 def test_abi_rejects_bad_arguments_without_gpu():

@@ -1,0 +1,73 @@
+"""CPU-side audit of the emitted gfx950 ISA of gemm.hip (no GPU needed: hipcc cross-compiles).
+
+Several GEMM kernels issue register-destination loads from inline asm so that hipcc does not track them (a tracked load
+makes it drain vmcnt to 0 where the value is first used, which would stall the LDS-DMA pipeline): the bias pair of
+gemm_px_kernel, the residual pieces of gemm_x3r_kernel, the residual rows of gemm_fp8p_kernel<RESID_F32>.  Their
+correctness rests on NO instruction touching a destination register before the hand-counted `s_waitcnt vmcnt` that covers
+the load -- which the source enforces by naming the registers as read-write operands of that wait statement, and which this
+test checks on the code the compiler actually emitted (tools/isa_async_reg_check.py: every path from each load, around
+backward branches too)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.isa_async_reg_check import audit  # noqa: E402
+
+SRC = os.path.join(ROOT, "hamer_yolo_amd", "csrc", "gemm.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def gemm_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("isa") / "gemm.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", SRC, "-o", out],
+                   check=True, capture_output=True, timeout=900)
+    return open(out).read()
+
+
+@pytest.mark.parametrize("kernel,min_loads", [
+    ("gemm_px_kernelI4TF16Li0E", 2), ("gemm_px_kernelI4TF16Li1E", 2), ("gemm_px_kernelI5TBf16Li0E", 2), ("gemm_px_kernelI5TBf16Li1E", 2),
+    ("gemm_x3r_kernelI4TF16E", 32), ("gemm_x3r_kernelI5TBf16E", 32),
+    ("gemm_fp8p_kernelILi2E", 16),
+])
+def test_asm_loaded_registers_are_fenced(gemm_isa, kernel, min_loads):
+    ok, report, n = audit(gemm_isa, kernel)
+    assert n >= min_loads, f"{kernel}: expected at least {min_loads} asm-issued register loads, found {n}\n{report}"
+    assert ok, report
+
+
+def test_audit_tool_catches_an_unfenced_use():
+    """The checker itself: a destination read with no hand-written wait on the path is a finding; behind one it is not; a
+    use reached only around a loop's back edge is still found."""
+    bad = """
+_Z3badv:
+\t;;#ASMSTART
+\tglobal_load_dword v5, v1, s[2:3]
+\t;;#ASMEND
+\tv_add_f32 v6, v5, v5
+\ts_endpgm
+"""
+    good = bad.replace("\tv_add_f32", "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_add_f32")
+    loop = """
+_Z4loopv:
+.LBB0_1:
+\tv_mov_b32 v9, v5
+\t;;#ASMSTART
+\tglobal_load_dword v5, v1, s[2:3]
+\t;;#ASMEND
+\ts_cbranch_scc1 .LBB0_1
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0)
+\t;;#ASMEND
+\tv_add_f32 v6, v5, v5
+\ts_endpgm
+"""
+    assert not audit(bad, "bad")[0]
+    assert audit(good, "bad")[0]
+    assert not audit(loop, "loop")[0]

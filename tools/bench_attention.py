@@ -2,6 +2,10 @@
 import sys, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import ops, lib as L
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 for B in (4, 8, 16, 32, 48, 64, 128):
     qkv = (torch.randn(B * 192, 3840, device="cuda") * 0.5).to(torch.bfloat16)
     for _ in range(5):

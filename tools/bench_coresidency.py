@@ -3,6 +3,10 @@ B, together vs apart, for GEMM tile variants with different register footprints 
 import sys, time, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import ops, lib as L
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 lib = L.load()
 M = 12288
 x = torch.randn(M, 5120, device="cuda").bfloat16(); w = (torch.randn(1280, 5120, device="cuda") * 0.02).bfloat16()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of GEMM tile variants on the ViT-H shapes (random data): ROUNDS rounds, every round runs
-every variant REPS times per shape; reports the median over all launches of a variant.  One process, one
+every variant REPS times per shape; reports the median over all launches of a variant (200 / 201: the default tile with
+the fp32 residual fetched in the epilogue / inside the K loop; >= 100 otherwise: default tile with group_m = v - 100).  One process, one
 device, variants interleaved so clock drift hits them equally.  Env: VARIANTS=8,9,10 ROUNDS=6 REPS=5"""
 import os
 import sys
@@ -27,12 +28,19 @@ if ONLY:
     shapes = [sh for sh in shapes if sh[0] in ONLY]
 if os.environ.get("EPI_STORE"):                # every shape with the plain 16-bit store epilogue (K-loop comparisons)
     shapes = [(n, k, nn, L.HM_EPI_STORE) for (n, k, nn, _) in shapes]
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 lib = L.load()
 res = {}
 
 
 def setv(v):
-    if v >= 100:
+    L.check(lib.hm_set_option(L.HM_OPT_RESID_IN_EPILOGUE, 1 if v == 200 else 0))
+    if v in (200, 201):             # 200 / 201: default tile with the fp32 residual fetched in the epilogue (round 2) / inside the K loop (round 3)
+        L.check(lib.hm_gemm_set_variant(-1)); L.check(lib.hm_gemm_set_group_m(8))
+    elif v >= 100:
         L.check(lib.hm_gemm_set_variant(-1)); L.check(lib.hm_gemm_set_group_m(v - 100))
     else:
         L.check(lib.hm_gemm_set_variant(v)); L.check(lib.hm_gemm_set_group_m(8))
@@ -46,6 +54,8 @@ for (name, K, N, epi) in shapes:
     f32 = epi == L.HM_EPI_RESID_F32
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else DT)
     r = torch.randn(M, N, device=dev) if f32 else None
+    if f32 and os.environ.get("COLD_RESID"):      # as in a forward: the residual stream comes from HBM, not from the Infinity Cache
+        flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     times = {v: [] for v in variants}
     for v in variants:                        # warm
         setv(v); ops.gemm(x, w, b, epi, resid=r, out=out)
@@ -55,6 +65,8 @@ for (name, K, N, epi) in shapes:
             setv(v)
             with L.profile(capacity=reps + 2) as prof:
                 for _ in range(reps):
+                    if f32 and os.environ.get("COLD_RESID"):
+                        flush.add_(1)                 # 512 MiB read + written: evicts the residual from the Infinity Cache
                     ops.gemm(x, w, b, epi, resid=r, out=out)
                 torch.cuda.synchronize()
             times[v] += [rec[5] for rec in prof.records]

@@ -3,6 +3,10 @@ import sys, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import ops, lib as L
 from oracle import fp8_ref as Q   # (tool only: builds test operands)
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 torch.manual_seed(0)
 def timeit(fn, n=20):
     for _ in range(5): fn()

@@ -3,6 +3,10 @@ import sys, time, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import synth
 from hamer_yolo_amd.engine import HamerEngine
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 cfg = synth.HamerConfig()
 sd = synth.hamer_state_dict(cfg, seed=0, device="cuda")
 eng = HamerEngine(sd, synth.mano_params(seed=0), cfg)

@@ -3,6 +3,10 @@ import sys, time, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import synth
 from hamer_yolo_amd.rootnet.engine import RootNetEngine
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 net, root = synth.rootnet_state_dict(0)
 eng = RootNetEngine(net, root)
 for B in (1, 4, 64):

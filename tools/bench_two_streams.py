@@ -15,6 +15,10 @@ NS = 4
 wss = [torch.empty(n, dtype=torch.uint8, device="cuda") for _ in range(NS)]
 outs = [eng.alloc_outputs(B) for _ in range(NS)]
 import os
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 PRI = os.environ.get("PRI", "0") == "1"
 streams = [torch.cuda.Stream(priority=(-1 if (PRI and i % 2 == 0) else 0)) for i in range(NS)]
 def run(nstreams, steps=40):

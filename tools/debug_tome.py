@@ -4,6 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamer_yolo_amd import synth
 from hamer_yolo_amd.engine import HamerEngine
 from oracle import tome_ref as T
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 cfg = synth.tome_tiny_config()
 sd = synth.hamer_state_dict(cfg, seed=7)
 mp = synth.mano_params(seed=0)

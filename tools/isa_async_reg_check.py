@@ -1,62 +1,99 @@
 #!/usr/bin/env python3
-"""Audit of loads issued from inline asm (global_load_dwordx4 into VGPRs the compiler does not track): for every such load
-print the first later instruction that touches one of its destination registers and the hand-written `s_waitcnt vmcnt`
-statements between the two.  A destination touched with no wait in between (a copy, a spill, an early use) would read
-stale data.  Usage: python tools/isa_async_reg_check.py file.s <mangled-name-substring>"""
+"""Audit of loads issued from inline asm into VGPRs the compiler does not track (global_load_dword / _dwordx2 / _dwordx4
+inside ;;#ASMSTART .. ;;#ASMEND): for every such load, walk every path the program can take from it -- straight on, and
+around every backward branch met on the way -- and report the first instruction that touches one of its destination
+registers together with the hand-written `s_waitcnt vmcnt` statements passed on that path.  A destination touched with no
+hand-written wait in between (a copy, a spill, an early use) would read stale data; the compiler's own waits do not count,
+it does not know about these loads.  LDS-DMA copies (global_load_lds_*) have no VGPR destination and are skipped.
+
+Usage: python tools/isa_async_reg_check.py file.s <mangled-name-substring>      (exit code 1 on a finding)
+       from tools.isa_async_reg_check import audit; ok, report, n_loads = audit(text, key)
+tests/test_isa_audit.py runs it on the emitted ISA of the GEMM kernels that use such loads."""
 import re
 import sys
 
-t = open(sys.argv[1]).read()
-m = re.search(r"^(_Z\S*" + re.escape(sys.argv[2]) + r"\S*):.*?\n(.*?)\n\s*s_endpgm", t, re.S | re.M)
-print(m.group(1))
-body = m.group(2).split("\n")
+_REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)\b")
+_LOAD = re.compile(r"global_load_dword(x2|x3|x4)?\s")
 
 
-def regs(tok):
-    mm = re.match(r"v\[(\d+):(\d+)\]", tok)
-    if mm:
-        return set(range(int(mm.group(1)), int(mm.group(2)) + 1))
-    mm = re.match(r"v(\d+)$", tok)
-    return {int(mm.group(1))} if mm else set()
+def _regs(text):
+    out = set()
+    for a, b, c in _REG.findall(text):
+        if c:
+            out.add(int(c))
+        else:
+            out |= set(range(int(a), int(b) + 1))
+    return out
 
 
-lines = []
-in_asm = False
-for i, l in enumerate(body):
-    s = l.strip()
-    if s.startswith(";;#ASMSTART"):
-        in_asm = True
-        continue
-    if s.startswith(";;#ASMEND"):
-        in_asm = False
-        continue
-    if not s or s.startswith((";", ".")):
-        continue
-    lines.append((i, s, in_asm))
-ok = True
-for k, (i, s, a) in enumerate(lines):
-    if not (a and s.startswith("global_load_dwordx4")):
-        continue
-    toks = re.findall(r"v\[\d+:\d+\]|v\d+", s)
-    dst = regs(toks[0])
-    waits = []
-    for (i2, s2, a2) in lines[k + 1:]:
-        if a2 and s2.startswith("s_waitcnt vmcnt"):
-            waits.append(s2.split()[1])
+def _dst(line):
+    m = _REG.search(line)
+    return _regs(m.group(0)) if m else set()
+
+
+def audit(text, key):
+    m = re.search(r"^(_Z\S*" + re.escape(key) + r"\S*):.*?\n(.*?)\n\s*s_endpgm", text, re.S | re.M)
+    if not m:
+        raise KeyError(f"no kernel matching {key!r}")
+    name, body = m.group(1), m.group(2).split("\n")
+    lines, labels, in_asm = [], {}, False
+    for raw in body:
+        s = raw.strip()
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
             continue
-        if a2 and s2.startswith("global_load_dwordx4"):
-            t2 = re.findall(r"v\[\d+:\d+\]|v\d+", s2)
-            if regs(t2[0]) & dst:
-                print(f"  line {i}: {toks[0]} overwritten by another asm load at {i2} before any use"); ok = False
-                break
-            continue                                   # (its address operand may be anything)
-        used = set()
-        for tk in re.findall(r"v\[\d+:\d+\]|v\d+", s2):
-            used |= regs(tk)
-        if used & dst:
-            flag = "ok" if waits else "NO WAIT"
-            if not waits:
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        lm = re.match(r"^(\.LBB\w+):", s)
+        if lm:
+            labels[lm.group(1)] = len(lines)
+            continue
+        if not s or s.startswith((";", ".")):
+            continue
+        lines.append((s.split(";")[0].strip(), in_asm))
+    report, ok, n_loads = [name], True, 0
+    for k, (s, a) in enumerate(lines):
+        if not (a and _LOAD.match(s)):
+            continue
+        n_loads += 1
+        dst = _dst(s)
+        # paths: (next index, stop index or None, hand-written waits seen so far); a backward branch adds the path label..k
+        todo, seen_labels, verdicts = [(k + 1, None, ())], set(), []
+        while todo:
+            i, stop, waits = todo.pop()
+            end = stop if stop is not None else len(lines)
+            while i < end:
+                s2, a2 = lines[i]
+                if a2 and s2.startswith("s_waitcnt") and "vmcnt" in s2:
+                    # a wait that names the registers as operands is itself the fence; it touches nothing
+                    waits = waits + (re.search(r"vmcnt\(\d+\)", s2).group(0),)
+                    i += 1
+                    continue
+                if a2 and _LOAD.match(s2):
+                    if _dst(s2) & dst:
+                        verdicts.append((bool(waits), f"overwritten by another asm load: {s2[:50]}", waits))
+                        break
+                    i += 1
+                    continue                               # (its address operand may be anything)
+                br = re.match(r"s_c?branch\S*\s+(\.LBB\w+)", s2)
+                if br and br.group(1) in labels and labels[br.group(1)] <= k and br.group(1) not in seen_labels:
+                    seen_labels.add(br.group(1))
+                    todo.append((labels[br.group(1)], k, waits))
+                if _regs(s2) & dst:
+                    verdicts.append((bool(waits), s2[:60], waits))
+                    break
+                i += 1
+        for good, what, waits in verdicts:
+            if not good:
                 ok = False
-            print(f"  line {i}: {toks[0]:12s} first touched at {i2}: {s2[:60]:60s} waits between: {waits} {flag}")
-            break
-print("all asm-loaded registers are first touched behind a hand-written wait" if ok else "PROBLEM")
+            report.append(f"  {s[:44]:44s} -> {what:60s} waits on the path: {list(waits)} {'ok' if good else 'NO WAIT'}")
+    report.append("all asm-loaded registers are first touched behind a hand-written wait" if ok else "PROBLEM")
+    return ok, "\n".join(report), n_loads
+
+
+if __name__ == "__main__":
+    good, rep, n = audit(open(sys.argv[1]).read(), sys.argv[2])
+    print(rep)
+    print(f"{n} asm-issued register loads audited")
+    sys.exit(0 if good else 1)

@@ -11,6 +11,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamer_yolo_amd import lib as L
 from hamer_yolo_amd import ops
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 
 M = 64 * 192
 DT = torch.float16

@@ -4,6 +4,10 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hamer_yolo_amd import lib as L, ops
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), 'tools'))
+from runlog import banner
+banner()
 
 M, N, K = 12288, 5120, 1280
 torch.manual_seed(0)

@@ -1,8 +1,13 @@
-"""hm_tome_attention: MFMA kernel vs the scalar fp32 kernel (HM_TOME_SCALAR_ATTENTION=1) vs an fp64 reference."""
+"""hm_tome_attention: MFMA kernel vs the scalar fp32 kernel (HM_OPT_TOME_SCALAR_ATTENTION) vs an fp64 reference."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hamer_yolo_amd import lib as L
 from hamer_yolo_amd import ops, synth
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), 'tools'))
+from runlog import banner
+banner()
 
 B, H, d = 3, 4, 80
 for tokens, with_size in ((192, False), (192, True), (176, True), (164, True), (155, True), (149, True), (23, True)):
@@ -13,10 +18,9 @@ for tokens, with_size in ((192, False), (192, True), (176, True), (164, True), (
     if with_size:
         a = a + size.double().reshape(B, 1, 1, tokens).log()
     ref = (a.softmax(-1) @ v).transpose(1, 2).reshape(B * tokens, H * d)
-    os.environ.pop("HM_TOME_SCALAR_ATTENTION", None)
     g1 = ops.tome_attention(qkv.cuda(), size.cuda() if with_size else None, B, tokens, H, d, d ** -0.5).double().cpu()
-    os.environ["HM_TOME_SCALAR_ATTENTION"] = "1"
-    g2 = ops.tome_attention(qkv.cuda(), size.cuda() if with_size else None, B, tokens, H, d, d ** -0.5).double().cpu()
+    with L.option(L.HM_OPT_TOME_SCALAR_ATTENTION, 1):
+        g2 = ops.tome_attention(qkv.cuda(), size.cuda() if with_size else None, B, tokens, H, d, d ** -0.5).double().cpu()
     mism = (g1 != g2).double().mean().item()
     r16 = ref.half().double()
     print(f"   bitwise mismatch mfma vs scalar {mism:.4f}; vs fp64->fp16: mfma {(g1 != r16).double().mean():.4f} scalar {(g2 != r16).double().mean():.4f}")

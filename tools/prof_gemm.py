@@ -8,6 +8,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hamer_yolo_amd import lib as L
 from hamer_yolo_amd import ops
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 
 M, N, K = int(os.environ.get("GM", 12288)), int(os.environ.get("GN", 1280)), int(os.environ.get("GK", 5120))
 epi = int(os.environ.get("EPI", L.HM_EPI_STORE))

@@ -1,28 +1,37 @@
-"""Per-shape time of the YOLOv7 convolutions for a batch of 1080p frames (hipEvent pairs per launch)."""
+"""Per-layer table of the YOLOv7 convolutions (hipEvent pairs per launch): for F frames of 1080p in one batched pass, every
+conv launch in network order with M, N, K, tile rows / columns, time and TFLOP/s, then the totals by kernel family.
+Usage: python tools/prof_yolo.py [frames=16] [reps=3]      (rocprofv3 --kernel-trace --stats -- python3 tools/prof_yolo.py 16)"""
 import sys, collections, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import synth, lib as L
 from hamer_yolo_amd.yolo.engine import YoloEngine
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__))))
+from runlog import banner
+banner()
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 eng = YoloEngine(synth.yolo_state_dict(seed=0, nc=3), nc=3, device="cuda")
 frames = [synth.frame_u8(1080, 1920, seed=i).cuda() for i in range(F)]
 for _ in range(3):
     eng.forward(frames)
 torch.cuda.synchronize()
 with L.profile(capacity=4096) as prof:
-    for _ in range(3):
+    for _ in range(REPS):
         eng.forward(frames)
     torch.cuda.synchronize()
-by = collections.defaultdict(lambda: [0, 0.0])
+recs = prof.records
+per_pass = len(recs) // REPS
 tot = collections.defaultdict(float)
-for kind, epi, M, N, K, ms in prof.records:
-    tot[kind] += ms / 3
-    if kind == "conv":
-        by[(epi, M, N, K)][0] += 1
-        by[(epi, M, N, K)][1] += ms / 3
-print({k: round(v, 3) for k, v in tot.items()})
-rows = sorted(by.items(), key=lambda kv: -kv[1][1])
-for (epi, M, N, K), (n, ms) in rows[:24]:
-    fl = 2.0 * M * N * K * (n / 3)
-    byts = (M * K / (9 if epi // 10 == 3 else 1) + M * N) * 2 * (n / 3)
-    print(f"k{epi//10}s{epi%10} M={M:7d} N={N:5d} K={K:5d} x{n//3:2d}: {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF  ~{byts/ms/1e9:6.2f} TB/s act")
+for kind, epi, M, N, K, ms in recs:
+    tot[kind] += ms / REPS
+print(f"frames={F}: ms per pass by kernel family:", {k: round(v, 3) for k, v in tot.items()})
+convs = [(i, r) for i, r in enumerate(recs[:per_pass]) if r[0] == "conv"]
+print(f"{'#':>3} {'k/s':>4} {'M':>8} {'N':>5} {'K':>5} {'us':>8} {'TF/s':>7}   (average of {REPS} passes)")
+cfl = cms = 0.0
+for j, (i, (kind, epi, M, N, K, ms)) in enumerate(convs):
+    t = sum(recs[i + p * per_pass][5] for p in range(REPS)) / REPS
+    fl = 2.0 * M * N * K
+    cfl += fl; cms += t
+    print(f"{j:3d} k{epi//10}s{epi%10} {M:8d} {N:5d} {K:5d} {t*1e3:8.1f} {fl/t/1e9:7.1f}")
+print(f"conv stack: {cms:.3f} ms per pass, {cfl/1e9:.1f} GFLOP, {cfl/cms/1e9:.1f} TFLOP/s ({cfl/cms/1e9/2500*100:.1f} % of the 2.5 PF 16-bit MFMA peak)")

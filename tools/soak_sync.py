@@ -4,6 +4,10 @@ the GEMM on exact-integer data, with the exact answer."""
 import sys, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import ops, lib as L
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), 'tools'))
+from runlog import banner
+banner()
 lib = L.load()
 bad = 0
 L.check(lib.hm_gemm_set_variant(24))
