@@ -5,8 +5,12 @@ The reference's drivers do ``from yolo.detector import Detector``, ``from hamer.
 ``from hamer.utils.renderer import custom_cam_crop_to_full``, ``from model.rootnet.Model_RGB import get_model``
 (hamer/infer.py:15-44, d_infer.py:21) with ``sys.path`` pointing into its checkout.  ``install()`` makes exactly those
 dotted names resolve to the modules of ``hamer_yolo_amd`` -- the SAME module objects, not second copies -- through a
-meta-path finder, so a caller of the reference switches by adding one line, ``import hamer_yolo_amd.compat``, before its
-own imports.  Nothing is installed when one of the names is already taken by another package.
+meta-path finder, so a caller of the reference switches by adding ``import hamer_yolo_amd.compat as compat;
+compat.install()`` before its own imports.  Importing this module installs nothing.
+
+The finder defers to the path finder: a name the caller's own ``sys.path`` can serve (its own ``config.py``, its own
+``model/`` package and every submodule found there) keeps resolving to the caller's code; only dotted names nobody else
+can find -- and the submodules of packages that already are this package's -- resolve to the aliases below.
 """
 from __future__ import annotations
 
@@ -34,9 +38,24 @@ class _AliasLoader(importlib.abc.Loader):
         pass
 
 
+def _others_can_find(fullname, path) -> bool:
+    try:
+        return importlib.machinery.PathFinder.find_spec(fullname, path) is not None
+    except (ImportError, ValueError):
+        return False
+
+
 class _AliasFinder(importlib.abc.MetaPathFinder):
     def find_spec(self, fullname, path=None, target=None):
-        if fullname == "model":                               # namespace parent of model.rootnet
+        top, _, _rest = fullname.partition(".")
+        parent = sys.modules.get(fullname.rpartition(".")[0]) if "." in fullname else None
+        ours = parent is not None and getattr(parent, "__name__", "").startswith("hamer_yolo_amd")
+        # the caller's own code wins: a top-level name its sys.path can serve, and any submodule found inside a package that
+        # is the caller's.  (Submodules of a package that IS one of this package's modules must be aliased here, first:
+        # the path finder would otherwise load a second copy of them under the alias name.)
+        if not ours and _others_can_find(fullname, path):
+            return None
+        if fullname == "model":                               # namespace parent of model.rootnet, when the caller has no `model` of its own
             spec = importlib.machinery.ModuleSpec("model", None, is_package=True)
             spec.submodule_search_locations = []
             return spec
@@ -67,7 +86,7 @@ def install() -> None:
         if mod is not None and not getattr(mod, "__name__", "").startswith("hamer_yolo_amd") and top != "model":
             raise ImportError(f"hamer_yolo_amd.compat: the name {top!r} is already imported from {getattr(mod, '__file__', '?')}")
     _finder = _AliasFinder()
-    sys.meta_path.insert(0, _finder)
+    sys.meta_path.insert(0, _finder)         # first, but it defers to the path finder for everything the caller's sys.path can serve
 
 
 def uninstall() -> None:
@@ -79,5 +98,3 @@ def uninstall() -> None:
     for name in [n for n in sys.modules if n == "model" or any(n == a or n.startswith(a + ".") for a in ALIASES)]:
         del sys.modules[name]
 
-
-install()

@@ -195,6 +195,18 @@ class HamerEngine:
         self.tokens = v.tokens
         self.n_verts = int(self.mano["v_template"].shape[0])
 
+    # ------------------------------------------------------------------ load-time check
+    def calibration_is_finite(self, n: int = 4) -> bool:
+        """One forward over `n` seeded crops (uniform u8 noise, ImageNet-normalised -- the full input range), checking that the
+        backbone tokens and every output are finite.  With fp16 operands the 16-bit intermediates (LayerNorm output, q / k / v,
+        the GELU output, to_kv) saturate at 65504 and an overflow turns into NaN poses without any other sign; the synthetic
+        weights stay far below that, a trained checkpoint is checked with this at load (HAMER.to)."""
+        from . import synth
+        img = synth.normalize_crops(synth.crops_u8(n, seed0=0)).to(self.device)
+        out = self.forward(img, want_tokens=self.tome_r is None)
+        torch.cuda.synchronize(self.device)
+        return all(bool(torch.isfinite(v.float()).all()) for v in out.values())
+
     # ------------------------------------------------------------------ run
     def workspace(self, B: int) -> torch.Tensor:
         if self._ws is None or self._ws_B < B:

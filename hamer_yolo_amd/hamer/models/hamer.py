@@ -71,6 +71,7 @@ class HAMER:
         self._sd = state_dict
         self._hc = hamer_cfg or engine_config(cfg, state_dict)
         self._engine: Optional[HamerEngine] = None
+        self.check_fp16_range = True   # one calibration forward at .to(device) (2 ms); set False to skip
         self._ws = {}                  # HIP stream -> (capacity in hands, workspace): forwards on different streams may overlap
         self.device = torch.device("cpu")
         self.training = False
@@ -83,6 +84,17 @@ class HAMER:
         if self._engine is None or self.device != device:
             self._engine = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=self.dtype,
                                        token_merge=self.token_merge or None)
+            # fp16 operands (the type that meets the 1e-3 bar) have a 65504 ceiling and no overflow detection: check once,
+            # at load, that this checkpoint's activations fit; if not, take the wider exponent and say so
+            if self.dtype == torch.float16 and self.check_fp16_range and not self._engine.calibration_is_finite():
+                import warnings
+                warnings.warn("HAMER: this checkpoint overflows fp16 GEMM operands on the calibration crops; falling back to "
+                              "bfloat16 operands (pose / shape within ~2e-3 of the fp32 reference instead of 2e-4)")
+                self.dtype = torch.bfloat16
+                self._engine = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=self.dtype,
+                                           token_merge=self.token_merge or None)
+                if not self._engine.calibration_is_finite():
+                    raise HipLibraryError("HAMER: non-finite outputs on the calibration crops with bfloat16 operands too: bad checkpoint?")
             self.device = device
         return self
 

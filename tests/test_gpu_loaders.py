@@ -141,3 +141,24 @@ def test_detector_from_checkpoint_file_equals_synthetic_route(tmp_path):
     pa, pf = det_a.engine._plan(1080, 1920)["pred"], det_f.engine._plan(1080, 1920)["pred"]
     assert torch.equal(pa[:, :2], pf[:, :2]) and torch.equal(pa[:, 4:], pf[:, 4:])
     np.testing.assert_allclose(pa[:, 2:4].cpu().numpy(), 1.5 * pf[:, 2:4].cpu().numpy(), rtol=1e-6)
+
+
+def test_fp16_overflow_is_detected_at_load_and_falls_back_to_bf16():
+    """the default operand type is fp16 (65504 ceiling, no overflow detection in the kernels).  HAMER.to() runs one
+    calibration forward; a checkpoint whose activations do not fit (here: a GELU input pushed to 1e5 by the fc1 bias of block
+    0) makes it warn and rebuild the engine with bfloat16 operands, whose outputs are finite."""
+    from hamer_yolo_amd.hamer.configs import get_config
+    from hamer_yolo_amd.hamer.models.mano_wrapper import MANO
+    cfg = synth.tiny_config()
+    sd = synth.hamer_state_dict(cfg, seed=0)
+    ok = HAMER(get_config(None), sd, MANO.synthetic(0), hamer_cfg=cfg).to("cuda")
+    assert ok.dtype == torch.float16                                   # the synthetic weights fit
+    bad = dict(sd)
+    bad["backbone.blocks.0.mlp.fc1.bias"] = sd["backbone.blocks.0.mlp.fc1.bias"] + 1e5
+    m = HAMER(get_config(None), bad, MANO.synthetic(0), hamer_cfg=cfg)
+    with pytest.warns(UserWarning, match="overflows fp16"):
+        m.to("cuda")
+    assert m.dtype == torch.bfloat16
+    img = synth.normalize_crops(synth.crops_u8(2, seed0=1)).cuda()
+    out, _ = m({"img": img})
+    assert torch.isfinite(out["pred_vertices"]).all()

@@ -391,13 +391,17 @@ def test_detect_anchors_come_from_the_checkpoint(golden_dir):
 
 
 def test_reference_import_names_resolve_to_this_package():
-    """the import lines of hamer/infer.py:15-44 and d_infer.py:21 work unchanged after ``import
-    hamer_yolo_amd.compat`` and give the same module objects as the package's own names (checked in a fresh interpreter so
-    the aliases do not leak into this test session)."""
+    """the import lines of hamer/infer.py:15-44 and d_infer.py:21 work unchanged after ``compat.install()`` and give
+    the same module objects as the package's own names (checked in a fresh interpreter so the aliases do not leak into this
+    test session).  The finder defers to the path finder: a caller's own ``config.py`` and ``model/`` package keep resolving to the
+    caller's code, and ``model.rootnet`` still falls through to this package."""
     import subprocess
     import sys
     code = r"""
-import hamer_yolo_amd.compat
+import sys
+import hamer_yolo_amd.compat as compat
+assert "yolo" not in sys.modules and not any(type(f).__name__ == "_AliasFinder" for f in sys.meta_path)   # importing installs nothing
+compat.install()
 from yolo.detector import Detector
 from hamer.models import load_hamer
 from hamer.models.mano_wrapper import MANO
@@ -417,6 +421,28 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    # a caller with its own config.py and model/ package: those win, model.rootnet still resolves to this package
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "config.py"), "w").write("MINE = 1\n")
+        os.makedirs(os.path.join(td, "model"))
+        open(os.path.join(td, "model", "__init__.py"), "w").write("")
+        open(os.path.join(td, "model", "other.py"), "w").write("X = 2\n")
+        code2 = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hamer_yolo_amd.compat as compat
+compat.install()
+import config, model.other
+assert config.MINE == 1 and model.other.X == 2 and not config.__name__.startswith("hamer_yolo_amd")
+from model.rootnet.Model_RGB import get_model
+import hamer_yolo_amd.rootnet.Model_RGB as R
+assert get_model is R.get_model
+from yolo.detector import Detector
+print("ok")
+""" % (root, td)
+        r = subprocess.run([sys.executable, "-c", code2], cwd=td, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
 
 
 def test_tome_schedule_parser_matches_oracle():
