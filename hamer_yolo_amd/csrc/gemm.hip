@@ -1308,9 +1308,13 @@ int launch_px(const KArgs& g, hipStream_t s) {
     g_px_grid = e ? atoi(e) : -1;
   }
   if (const int o = hm_option(HM_OPT_PX_GRID)) g_px_grid = o;      // explicit setter (hm_set_option) wins
-  // (Leaving 16 of the 256 CUs to the other stream's LayerNorm / attention workgroups -- 240 workgroups: the same number of
-  // tile-times for 720 / 960 tiles -- was measured neutral with two batches in flight: 3656-3673 hands/s at 224 / 240 / 248 / 256.)
-  int want = g_px_grid > 0 ? g_px_grid : cus;
+  // Default: one workgroup per CU on all but ONE CU of every XCD (248 of 256).  Round 3, interleaved whole-model A/B in one
+  // process (tools/bench_model_ab.py, profiles/r03_model_ab_px_grid.log): a lone forward takes 18.50 ms with 240 or 248
+  // workgroups against 19.84 with 256 -- the same number of tile rounds for qkv / fc1 (720 / 960 tiles), so it is not
+  // quantisation: a 256-workgroup persistent kernel needs every CU of the chip at once, and whichever CU is late (the previous
+  // kernel's last waves, the dispatcher) delays one workgroup's whole run of tiles.  With two batches in flight the other
+  // stream filled that hole already (17.55 ms either way).
+  int want = g_px_grid > 0 ? g_px_grid : (cus >= 64 ? cus - 8 : cus);
   if (want > cus) want = cus;
   const int grid = (tiles < want ? tiles : want) & ~7;             // a multiple of the 8 XCDs
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);

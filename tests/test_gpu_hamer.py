@@ -16,6 +16,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from hamer_yolo_amd import lib as L
 from hamer_yolo_amd import synth
 from hamer_yolo_amd.engine import HamerEngine
 from oracle import hamer_ref as R

@@ -38,7 +38,11 @@ for item in [c for c in spec.split(";") if c]:
     name, nfl, opts = item.split(":")
     o = dict(kv.split("=") for kv in opts.split(",") if kv)
     eng = engine(o.get("fold_ln") == "1")
-    configs.append((name, int(nfl), o, eng, eng.contexts(B, int(nfl))))
+    configs.append((name, int(nfl), o, eng, None))
+# ONE set of contexts (HIP streams, workspaces) per engine, shared by every configuration: streams map onto a few hardware
+# queues, and two configurations on different stream pairs do not overlap alike
+ctx_of = {id(e): e.contexts(B, max(c[1] for c in configs if c[3] is e)) for e in engines.values()}
+configs = [(n, k, o, e, ctx_of[id(e)][:k]) for (n, k, o, e, _) in configs]
 img = synth.normalize_crops(synth.crops_u8(B, seed0=0)).cuda()
 
 

@@ -5,8 +5,6 @@ O=gpurun_out/r03b; mkdir -p $O
 step() { echo "== $*" | tee -a $O/steps.log; }
 step model_ab; ROUNDS=5 STEPS=20 timeout -k 10 600 python tools/bench_model_ab.py > $O/model_ab.log 2>&1 || { tail -5 $O/model_ab.log; exit 1; }
 cat $O/model_ab.log
-step hands; timeout -k 10 300 python tools/probes/yolo_hands_per_frame.py -2.45 -2.5 -2.53 -2.56 > $O/hands_per_frame.log 2>&1 || exit 1
-cat $O/hands_per_frame.log
-step bench; /usr/bin/time -v timeout -k 10 900 python bench.py > $O/bench.json.log 2>$O/bench.err || { tail -20 $O/bench.err; exit 1; }
-cat $O/bench.json.log; grep -E "Elapsed|Maximum resident" $O/bench.err
-step tests; /usr/bin/time -v timeout -k 10 1100 python -m pytest tests -q -m gpu > $O/t_all.log 2>&1; rc=$?; tail -8 $O/t_all.log; [ $rc -le 1 ] || exit $rc
+step bench; SECONDS=0; timeout -k 10 900 python bench.py > $O/bench.json.log 2>$O/bench.err || { tail -20 $O/bench.err; exit 1; }
+cat $O/bench.json.log; echo "bench.py wall: $SECONDS s"
+step tests; timeout -k 10 1100 python -m pytest tests -q -m gpu > $O/t_all.log 2>&1; rc=$?; tail -8 $O/t_all.log; [ $rc -le 1 ] || exit $rc
