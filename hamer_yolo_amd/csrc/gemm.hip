@@ -388,8 +388,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   int tm, tn;
   const int wgid = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = (EPI == HM_EPI_F32 && !CONV) ? wgid % g.ksplit : 0;   // which K range (split-K: ksplit > 1)
-  tile_coords((EPI == HM_EPI_F32 && !CONV) ? wgid / g.ksplit : wgid, tiles_m, tiles_n, g.group_m, tm, tn);
+  const int split = EPI == HM_EPI_F32 ? wgid % g.ksplit : 0;   // which K range (split-K: ksplit > 1)
+  tile_coords(EPI == HM_EPI_F32 ? wgid / g.ksplit : wgid, tiles_m, tiles_n, g.group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int wr = wave / WN, wc = wave % WN;
 
@@ -427,12 +427,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     wsrc[i] = W + (size_t)gn * g.ldw + chunk * 8;
   }
 
+  const int nk = EPI == HM_EPI_F32 ? g.K / BK / g.ksplit : g.K / BK;
+  const int kt0 = split * nk;                           // split-K: this workgroup's K range starts kt0 tiles in
   auto stage = [&](int buf, int kt) {
     if (SCHED == 93) return;                            // ablation: no global loads at all
     char* lx = smem + buf * STAGE_BYTES + wave * XI * 1024;
     char* lw = smem + buf * STAGE_BYTES + XTILE_BYTES + wave * WI * 1024;
     if (CONV) {
-      const int k = kt * BK + chunk * 8;
+      const int k = (kt0 + kt) * BK + chunk * 8;
       const int tap = k >> g.cin_log2, ci = k & ((1 << g.cin_log2) - 1);
       const int ky = tap / g.ksz, kx = tap - ky * g.ksz;
 #pragma unroll
@@ -478,12 +480,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   };
 
   // ---- K loop: ring of STAGES buffers, STAGES-1 tiles of LDS-DMA in flight across the barrier
-  const int nk = (EPI == HM_EPI_F32 && !CONV) ? g.K / BK / g.ksplit : g.K / BK;
-  if (EPI == HM_EPI_F32 && !CONV) {                     // this workgroup's K range starts split * nk tiles in
+  if (EPI == HM_EPI_F32) {                              // (the implicit-GEMM X loader takes kt0 itself: its address is per tap)
+    if (!CONV) {
 #pragma unroll
-    for (int i = 0; i < XI; ++i) xsrc[i] += (size_t)split * nk * BK;
+      for (int i = 0; i < XI; ++i) xsrc[i] += (size_t)kt0 * BK;
+    }
 #pragma unroll
-    for (int i = 0; i < WI; ++i) wsrc[i] += (size_t)split * nk * BK;
+    for (int i = 0; i < WI; ++i) wsrc[i] += (size_t)kt0 * BK;
   }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -1797,7 +1800,7 @@ int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
   auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED>;
   static HmLdsOnce lds_once;
   if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * ((EPI == HM_EPI_F32 && !CONV) ? g.ksplit : 1);
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == HM_EPI_F32 ? g.ksplit : 1);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, s, g);
   return hm_check_launch(what);
 }
@@ -1929,26 +1932,117 @@ int launch_gemm_epi(const KArgs& g, int epilogue, hipStream_t s) {
   }
 }
 
-// N-tile of the convolution: as wide as Cout allows (128 / 64 / 32 columns), but narrower when that leaves most CUs without a
-// tile -- the 12x20 and 24x40 maps of the YOLOv7 head have 30-120 row tiles per 16 frames, and K = 2304..4608 is long
+// Convolution tiles.  Round 2 had the 128-row, four-wave, two-workgroups-per-CU tile only (128 x 128 / 64 / 32); round 3 adds the
+// eight-wave 256-row tiles of the ViT GEMM (256 x 256 / 128 / 64: half the operand bytes per flop) for the layers whose output
+// has enough of them to fill the chip, and split-K (below) for the layers that have too few tiles of any shape.
+enum { CT_128x128 = 0, CT_128x64 = 1, CT_128x32 = 2, CT_256x128 = 3, CT_256x256 = 4, CT_256x64 = 5,
+       CT_128x32_D = 6, CT_128x64_D = 7, CT_128x128_D = 8, CT_COUNT = 9 };      // _D: deep ring (4 / 4 / 3 stages) for lone workgroups
+constexpr int ct_bm(int t) { return (t >= CT_256x128 && t <= CT_256x64) ? 256 : 128; }
+constexpr int ct_bn(int t) {
+  return (t == CT_128x128 || t == CT_256x128 || t == CT_128x128_D) ? 128 : (t == CT_256x256 ? 256 : ((t == CT_128x32 || t == CT_128x32_D) ? 32 : 64));
+}
+
+int conv_tiles(const KArgs& g, int t) { return ((g.M + ct_bm(t) - 1) / ct_bm(t)) * ((g.N + ct_bn(t) - 1) / ct_bn(t)); }
+
+// Tile choice, from per-layer sweeps of the YOLOv7 shapes with every tile forced in turn (tools/prof_yolo.py with CONV_TILE;
+// profiles/r03_yolo_tile_sweep_*.txt; HM_OPT_CONV_TILE forces one):
+//  * 256 x 256 (the ViT tile) wins by ~10 % where Cout >= 256 and its tiles fill the chip; 256 x 128 / 256 x 64 never won
+//    (they stay selectable for sweeps);
+//  * otherwise the 128-row tiles, two to four workgroups per CU, narrowed while most CUs would stay without a tile;
+//  * when even the narrow tile leaves at most one workgroup per CU, nothing hides the global -> LDS round trip of a two-stage
+//    ring (0.8 us per 64-deep K-step measured on the 12x20 maps): those layers take the deep ring (`ks` = K ranges of split-K).
+int pick_conv_tile(const KArgs& g, int ks_hint = 1) {
+  const int forced = hm_option(HM_OPT_CONV_TILE);
+  if (forced > 0 && forced <= CT_COUNT) return forced - 1;
+  if (g.N >= 256 && conv_tiles(g, CT_256x256) >= 200) return CT_256x256;
+  int t = g.N > 64 ? CT_128x128 : (g.N > 32 ? CT_128x64 : CT_128x32);
+  while (t < CT_128x32 && conv_tiles(g, t) < 192) ++t;
+  if (conv_tiles(g, t) * ks_hint <= 288 && g.K >= 4 * 64) t = t == CT_128x128 ? CT_128x128_D : (t == CT_128x64 ? CT_128x64_D : CT_128x32_D);
+  return t;
+}
+
 template <class T, int EPI>
-int launch_conv_ni(const KArgs& g, hipStream_t s) {
-  const int tiles_m = (g.M + 127) / 128;
-  int bn = g.N > 64 ? 128 : (g.N > 32 ? 64 : 32);
-  while (bn > 32 && tiles_m * ((g.N + bn - 1) / bn) < 192) bn >>= 1;
-  if (bn == 128) return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true>(g, s, "hm_conv2d_nhwc");
-  if (bn == 64) return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true>(g, s, "hm_conv2d_nhwc");
-  return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true>(g, s, "hm_conv2d_nhwc");
+int launch_conv_tile(const KArgs& g, int t, hipStream_t s) {
+  switch (t) {
+    case CT_128x128: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true>(g, s, "hm_conv2d_nhwc");
+    case CT_128x64: return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true>(g, s, "hm_conv2d_nhwc");
+    case CT_128x32: return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true>(g, s, "hm_conv2d_nhwc");
+    case CT_256x128: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, true, 64, 2>(g, s, "hm_conv2d_nhwc");
+    case CT_256x256: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, true, 64, 2>(g, s, "hm_conv2d_nhwc");
+    case CT_256x64: return launch_cfg<T, EPI, 4, 2, 4, 2, 2, true, 64, 2>(g, s, "hm_conv2d_nhwc");
+    case CT_128x32_D: return launch_cfg<T, EPI, 2, 2, 4, 1, 4, true>(g, s, "hm_conv2d_nhwc");      // 4 x 20 KB
+    case CT_128x64_D: return launch_cfg<T, EPI, 2, 2, 4, 2, 4, true>(g, s, "hm_conv2d_nhwc");      // 4 x 24 KB
+    case CT_128x128_D: return launch_cfg<T, EPI, 2, 2, 4, 4, 3, true>(g, s, "hm_conv2d_nhwc");     // 3 x 32 KB
+    default: return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unknown tile");
+  }
+}
+
+// Split-K for convolutions with few output tiles and a long K (the 12x20 / 24x40 maps of the YOLOv7 neck: 30-120 row tiles,
+// K = 2304..4608): the K tiles are cut into `ks` ranges, each range's workgroups write an fp32 partial slab [ks][M][N] into
+// the caller's workspace (HM_EPI_F32 path of the kernel), and one small kernel adds the slabs in order, adds the bias, applies
+// the activation and writes the 16-bit NHWC result.  Deterministic (fixed summation order), no atomics.
+template <class T, int ACT>     // ACT: 0 none, 1 SiLU, 2 ReLU
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                  typename T::elem* __restrict__ y, int M, int N, int ldy, int ks) {
+  const int n8 = N >> 3;                                   // host: N % 8 == 0
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * n8) return;
+  const int m = (int)(i / n8), n = (int)(i - (size_t)m * n8) * 8;
+  f32x4_t a0 = *(const f32x4_t*)(bias + n), a1 = *(const f32x4_t*)(bias + n + 4);
+  f32x4_t s0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  for (int s = 0; s < ks; ++s) {
+    const float* p = part + ((size_t)s * M + m) * N + n;
+    s0 += *(const f32x4_t*)p; s1 += *(const f32x4_t*)(p + 4);
+  }
+  typename T::vec8 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float u = __fadd_rn(s0[q], a0[q]), v = __fadd_rn(s1[q], a1[q]);          // acc + bias, then the activation: as the fused epilogue rounds
+    if (ACT == 1) { u = silu(u); v = silu(v); }
+    if (ACT == 2) { u = fmaxf(u, 0.f); v = fmaxf(v, 0.f); }
+    o[q] = (typename T::elem)u; o[4 + q] = (typename T::elem)v;
+  }
+  *(typename T::vec8*)(y + (size_t)m * ldy + n) = o;
+}
+
+// K ranges for a convolution: only when the best tile leaves most of the chip idle and K is long; whole 64-deep K tiles per range
+int pick_conv_split(const KArgs& g, int tile, size_t ws_bytes) {
+  const int forced = hm_option(HM_OPT_CONV_SPLITK);
+  const int tiles = conv_tiles(g, tile), nk = g.K / 64;
+  if (forced == 1 || g.N % 8 != 0 || (g.ldc & 7) != 0 || tiles > 128 || nk < 8) return 1;
+  int want = forced > 1 ? forced : 256 / tiles;
+  if (want > 8) want = 8;
+  if (want > nk / 4) want = nk / 4;                        // at least 4 K tiles per range: the ring's start-up is two tiles
+  while (want > 1 && nk % want != 0) --want;
+  while (want > 1 && (size_t)want * g.M * g.N * 4 > ws_bytes) --want;
+  while (want > 1 && nk % want != 0) --want;
+  return want < 1 ? 1 : want;
 }
 
 template <class T>
-int launch_conv(const KArgs& g, int epilogue, hipStream_t s) {
+int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStream_t s) {
+  KArgs g = g0;
+  const bool act_ok = epilogue == HM_EPI_STORE || epilogue == HM_EPI_SILU || epilogue == HM_EPI_RELU;
+  const int ks = (ws && g.bias && act_ok && (((uintptr_t)ws) & 15) == 0) ? pick_conv_split(g, pick_conv_tile(g), ws_bytes) : 1;
+  const int t = pick_conv_tile(g, ks);
+  if (ks > 1) {
+    void* y = g.C; const int ldy = g.ldc; const float* bias = g.bias;
+    g.C = ws; g.ldc = g.N; g.bias = nullptr; g.ksplit = ks;
+    if (const int rc = launch_conv_tile<T, HM_EPI_F32>(g, t, s)) return rc;
+    const size_t n = (size_t)g.M * (g.N >> 3);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    using elem = typename T::elem;
+    if (epilogue == HM_EPI_SILU) hipLaunchKernelGGL((conv_splitk_reduce_kernel<T, 1>), grid, dim3(256), 0, s, (const float*)ws, bias, (elem*)y, g.M, g.N, ldy, ks);
+    else if (epilogue == HM_EPI_RELU) hipLaunchKernelGGL((conv_splitk_reduce_kernel<T, 2>), grid, dim3(256), 0, s, (const float*)ws, bias, (elem*)y, g.M, g.N, ldy, ks);
+    else hipLaunchKernelGGL((conv_splitk_reduce_kernel<T, 0>), grid, dim3(256), 0, s, (const float*)ws, bias, (elem*)y, g.M, g.N, ldy, ks);
+    return hm_check_launch("hm_conv2d_nhwc (split-K reduce)");
+  }
   switch (epilogue) {
-    case HM_EPI_STORE: return launch_conv_ni<T, HM_EPI_STORE>(g, s);
-    case HM_EPI_SILU: return launch_conv_ni<T, HM_EPI_SILU>(g, s);
-    case HM_EPI_F32: return launch_conv_ni<T, HM_EPI_F32>(g, s);
-    case HM_EPI_RELU: return launch_conv_ni<T, HM_EPI_RELU>(g, s);
-    case HM_EPI_ADD_RELU: return launch_conv_ni<T, HM_EPI_ADD_RELU>(g, s);
+    case HM_EPI_STORE: return launch_conv_tile<T, HM_EPI_STORE>(g, t, s);
+    case HM_EPI_SILU: return launch_conv_tile<T, HM_EPI_SILU>(g, t, s);
+    case HM_EPI_F32: return launch_conv_tile<T, HM_EPI_F32>(g, t, s);
+    case HM_EPI_RELU: return launch_conv_tile<T, HM_EPI_RELU>(g, t, s);
+    case HM_EPI_ADD_RELU: return launch_conv_tile<T, HM_EPI_ADD_RELU>(g, t, s);
     default: return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unsupported epilogue");
   }
 }
@@ -2083,8 +2177,9 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   if (c.out_f32 && c.act) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: f32 output has no activation");
   k.resid16 = c.resid; k.ldr16 = c.ldr;
   const int epi = c.out_f32 ? HM_EPI_F32 : (c.act == 1 ? HM_EPI_SILU : (c.act == 2 ? (c.resid ? HM_EPI_ADD_RELU : HM_EPI_RELU) : HM_EPI_STORE));
+  k.ksplit = 1;
   HmProfScope prof(HM_K_CONV, c.ksize * 10 + c.stride, k.M, k.N, ktrue, stream);
-  if (c.dtype == HM_DTYPE_BF16) return launch_conv<TBf16>(k, epi, stream);
-  if (c.dtype == HM_DTYPE_F16) return launch_conv<TF16>(k, epi, stream);
+  if (c.dtype == HM_DTYPE_BF16) return launch_conv<TBf16>(k, epi, c.splitk_ws, c.splitk_ws_bytes, stream);
+  if (c.dtype == HM_DTYPE_F16) return launch_conv<TF16>(k, epi, c.splitk_ws, c.splitk_ws_bytes, stream);
   return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: bad dtype");
 }

@@ -17,7 +17,7 @@ HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 
 HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU, HM_EPI_GELU_MX8 = 5, 6, 7, 8
 HM_VERSION = 300      # include/hamer_hip.h: load() refuses a library built from another header
 (HM_OPT_PX_GRID, HM_OPT_FP8P_GRID, HM_OPT_FP8_ONE_TILE, HM_OPT_FP8P_RESID, HM_OPT_TOME_NO_SPLITK,
- HM_OPT_TOME_SCALAR_ATTENTION, HM_OPT_RESID_IN_EPILOGUE) = range(7)
+ HM_OPT_TOME_SCALAR_ATTENTION, HM_OPT_RESID_IN_EPILOGUE, HM_OPT_CONV_TILE, HM_OPT_CONV_SPLITK) = range(9)
 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
@@ -87,7 +87,7 @@ class HamerWeights(C.Structure):
 class ConvArgs(C.Structure):
     _fields_ = [("X", vp), ("W", vp), ("Y", vp), ("bias", vp), ("zeros", vp)] + \
                [(n, C.c_int) for n in ("N", "H", "W_in", "Cin", "Cout", "ksize", "stride", "ldx", "ldy", "Kpad", "act",
-                                       "out_f32", "dtype")] + [("resid", vp), ("ldr", C.c_int)]
+                                       "out_f32", "dtype")] + [("resid", vp), ("ldr", C.c_int), ("splitk_ws", vp), ("splitk_ws_bytes", C.c_size_t)]
 
 
 class YoloOp(C.Structure):

@@ -69,6 +69,9 @@ class YoloEngine:
         self.anchors = detect_anchors(state_dict)            # pixels, per level: the checkpoint's anchor_grid (yolo.py:164)
         self.names = list(names) if names is not None else [str(i) for i in range(nc)]   # Model.names of the checkpoint
         self._plans: Dict[Tuple[int, int], dict] = {}
+        self._stacked: Dict[Tuple[str, str], Tuple[torch.Tensor, torch.Tensor]] = {}   # stacked weights of fused 1x1 pairs
+        self.fuse_pairs = True        # E-ELAN cv1 / cv2 as one launch (round 3); False: one launch per convolution, as the reference's graph
+        self.split_k = True           # give the library split-K scratch for the small maps of the neck (round 3)
 
     # ------------------------------------------------------------------ planning
     def _plan(self, H: int, W: int, nb: int = 1) -> dict:
@@ -130,6 +133,13 @@ class YoloEngine:
         arena = torch.zeros(total, dtype=torch.uint8, device=self.device)
         base = arena.data_ptr()
         esz = 2
+        # split-K scratch (hm_conv_args.splitk_ws): shared by all layers of the plan, sized for 8 fp32 slabs of the largest output
+        # among the layers small enough to be split (<= 128 tiles of 128 x 128), capped at 128 MB; the library uses what fits
+        small = [nb * hw[i][0] * hw[i][1] * ch[i] for i, (_, kind, _a) in enumerate(layers)
+                 if kind in ("conv", "repconv", "sppcspc") and nb * hw[i][0] * hw[i][1] * ch[i] <= 128 * 128 * 128]
+        ws_bytes = min(128 << 20, 8 * 4 * max(small)) if (small and self.split_k) else 0
+        splitk_ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.device)
+        ws_ptr = splitk_ws.data_ptr() if ws_bytes else None
 
         def addr(buf, ch_off=0):
             return base + offs[buf] + ch_off * esz
@@ -139,14 +149,45 @@ class YoloEngine:
             return addr(b, o), ld
 
         ops: List[L.YoloOp] = []
+        pending = []                                           # convolutions in launch order, before pair fusion
 
         def conv(name, xptr, ldx, h, w, yptr, ldy, act=1, out_f32=0):
-            wt, bs, cin, k, s, co = self.w[name]
+            pending.append(("conv", name, xptr, ldx, h, w, yptr, ldy, act, out_f32))
+
+        def emit_conv(wt, bs, cin, k, s, co, xptr, ldx, h, w, yptr, ldy, act, out_f32):
             a = L.ConvArgs(xptr, wt.data_ptr(), yptr, bs.data_ptr(), self.zeros.data_ptr(), nb, h, w, cin, co, k, s, ldx, ldy,
-                           wt.shape[1], act, out_f32, self.dt)
+                           wt.shape[1], act, out_f32, self.dt, None, 0, ws_ptr, ws_bytes)
             ops.append(L.YoloOp(0, 0, a))
 
+        def flush():
+            """Emit the pending convolutions.  Two consecutive 1x1 convolutions that read the SAME tensor and write ADJACENT
+            channel slices of one buffer -- cv1 / cv2 at the head of every E-ELAN block (yolov7.yaml: `[-1, 1, Conv, ..]`,
+            `[-2, 1, Conv, ..]`, both into the block's Concat) -- become ONE launch with the weight rows stacked: same
+            arithmetic per output channel, one pass over the input instead of two, a wider N tile."""
+            i = 0
+            while i < len(pending):
+                _, name, xptr, ldx, h, w, yptr, ldy, act, out_f32 = pending[i]
+                wt, bs, cin, k, s, co = self.w[name]
+                if self.fuse_pairs and i + 1 < len(pending):
+                    _, name2, xptr2, ldx2, h2, w2, yptr2, ldy2, act2, out2 = pending[i + 1]
+                    wt2, bs2, cin2, k2, s2, co2 = self.w[name2]
+                    same_in = (xptr2, ldx2, h2, w2, cin2, k2, s2, act2, out2, ldy2) == (xptr, ldx, h, w, cin, 1, 1, act, out_f32, ldy)
+                    if same_in and k == 1 and s == 1 and not out_f32 and (yptr == yptr2 + co2 * esz or yptr2 == yptr + co * esz):
+                        first_is_2 = yptr == yptr2 + co2 * esz
+                        key = (name2, name) if first_is_2 else (name, name2)
+                        if key not in self._stacked:
+                            a_, b_ = (self.w[key[0]], self.w[key[1]])
+                            self._stacked[key] = (torch.cat([a_[0], b_[0]], 0).contiguous(), torch.cat([a_[1], b_[1]], 0).contiguous())
+                        wst, bst = self._stacked[key]
+                        emit_conv(wst, bst, cin, 1, 1, co + co2, xptr, ldx, h, w, yptr2 if first_is_2 else yptr, ldy, act, 0)
+                        i += 2
+                        continue
+                emit_conv(wt, bs, cin, k, s, co, xptr, ldx, h, w, yptr, ldy, act, out_f32)
+                i += 1
+            pending.clear()
+
         def pool(xptr, ldx, h, w, c, yptr, ldy, k, s, pad):
+            flush()
             a = L.ConvArgs(xptr, None, yptr, None, None, nb, h, w, c, c, k, s, ldx, ldy, 0, 0, 0, self.dt)
             ops.append(L.YoloOp(1, pad, a))
 
@@ -168,6 +209,7 @@ class YoloEngine:
                 pool(xptr, ldx, h, w, ch[s0], yptr, ldy, 2, 2, 0)
             elif kind == "up":
                 yptr, ldy = loc(i)
+                flush()
                 a = L.ConvArgs(xptr, None, yptr, None, None, nb, h, w, ch[s0], ch[s0], 1, 1, ldx, ldy, 0, 0, 0, self.dt)
                 ops.append(L.YoloOp(2, 0, a))
             elif kind == "sppcspc":                          # common.py:279-284
@@ -189,6 +231,7 @@ class YoloEngine:
                     raw = torch.empty(nb * hh * ww, 3 * self.no, dtype=torch.float32, device=self.device)
                     raws.append((raw, hh, ww))
                     conv(f"model.{i}.m.{l}", xp, ldxx, hh, ww, raw.data_ptr(), 3 * self.no, act=0, out_f32=1)
+        flush()
         op_arr = (L.YoloOp * len(ops))(*ops)
         n_pred = sum(3 * hh * ww for _, hh, ww in raws)
         plan = {
@@ -199,7 +242,7 @@ class YoloEngine:
             "count": torch.zeros(nb, dtype=torch.int32, device=self.device),
             "nms_ws": torch.empty(self.lib.hm_nms_workspace_bytes(n_pred), dtype=torch.uint8, device=self.device),
             "u8": torch.empty(3, lp.out_h, lp.out_w, dtype=torch.uint8, device=self.device),
-            "home": home, "hw": hw, "ch": ch, "offs": offs,
+            "home": home, "hw": hw, "ch": ch, "offs": offs, "splitk_ws": splitk_ws,
         }
         self._plans[key] = plan
         return plan

@@ -93,7 +93,9 @@ enum {
   HM_OPT_TOME_NO_SPLITK = 4,        /* 1: token-merging forward never splits proj / fc2 over K (tests compare the routes) */
   HM_OPT_TOME_SCALAR_ATTENTION = 5, /* 1: hm_tome_attention takes the fp32 lane-per-key kernel                           */
   HM_OPT_RESID_IN_EPILOGUE = 6,     /* 1: the fp32-residual GEMM fetches its residual rows in the epilogue (round-2 form) */
-  HM_OPT_COUNT = 7
+  HM_OPT_CONV_TILE = 7,             /* tuning: force convolution tile (1..9 = 128x128, 128x64, 128x32, 256x128, 256x256, 256x64, then the deep-ring 128x32, 128x64, 128x128); 0 = per-layer choice */
+  HM_OPT_CONV_SPLITK = 8,           /* tuning: 1 = never split a convolution over K, n > 1 = ask for n ranges where splitting applies; 0 = automatic */
+  HM_OPT_COUNT = 9
 };
 int hm_set_option(int key, int value);
 int hm_get_option(int key);
@@ -303,6 +305,11 @@ typedef struct hm_conv_args {
   int dtype;
   const void* resid;  /* optional with act == 2: [N][Hout][Wout][ldr] 16-bit added before the ReLU (BasicBlock identity) */
   int ldr;
+  /* round 3, optional: scratch for split-K (few output tiles, long K: the small maps of the YOLOv7 neck).  When given (16-byte
+   * aligned), the library may cut K into up to 8 ranges that write fp32 partial slabs [ranges][N*Hout*Wout][Cout] here and add
+   * them, in order, in a second small kernel; 8 * N*Hout*Wout * Cout * 4 bytes always suffice, less is used as it fits. */
+  void* splitk_ws;
+  size_t splitk_ws_bytes;
 } hm_conv_args;
 
 /* Conv2d(k in {1,3,5,7}, stride in {1,2}, pad k/2) + bias (+ SiLU / ReLU / residual add + ReLU) as an implicit GEMM on MFMA.

@@ -20,7 +20,7 @@ from oracle import yolo_ref
 DEV = "cuda"
 
 
-def _conv_gpu(x_nchw, w, b, k, s, act, dt, out_f32=False, ld_extra=0, y_extra=0):
+def _conv_gpu(x_nchw, w, b, k, s, act, dt, out_f32=False, ld_extra=0, y_extra=0, splitk_ws=None):
     """Run hm_conv2d_nhwc on an NHWC copy (optionally inside wider buffers to exercise strides)."""
     lib = L.load()
     N, Ci, H, W = x_nchw.shape
@@ -40,7 +40,8 @@ def _conv_gpu(x_nchw, w, b, k, s, act, dt, out_f32=False, ld_extra=0, y_extra=0)
     esz = 2
     a = L.ConvArgs(xd.data_ptr() + ld_extra * esz, wd.data_ptr(), yd.data_ptr() + y_extra * (4 if out_f32 else 2), bd.data_ptr(),
                    zeros.data_ptr(), N, H, W, cin, Co, k, s, cin + ld_extra, Co + y_extra, kp, int(act), int(out_f32),
-                   L.HM_DTYPE_BF16 if dt == torch.bfloat16 else L.HM_DTYPE_F16)
+                   L.HM_DTYPE_BF16 if dt == torch.bfloat16 else L.HM_DTYPE_F16, None, 0,
+                   splitk_ws.data_ptr() if splitk_ws is not None else None, splitk_ws.numel() if splitk_ws is not None else 0)
     L.check(lib.hm_conv2d_nhwc(C.byref(a), L.current_stream()), "hm_conv2d_nhwc")
     torch.cuda.synchronize()
     y = yd.cpu().float()
@@ -69,6 +70,83 @@ def test_conv_exact_integer_data():
     ref = F.conv2d(x, w, torch.zeros(32), stride=1, padding=1)
     y = _conv_gpu(x, w, torch.zeros(32), 3, 1, act=False, dt=torch.float16, out_f32=True)
     assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+def test_conv_every_tile_exact_and_equal(tile):
+    """Round 3: the convolution runs on nine tiles (128 x 128 / 64 / 32 with four waves and a two-stage ring, 256 x 128 / 256 / 64 with
+    eight, the 128-row ones again with a three- / four-stage ring for lone workgroups), chosen
+    per layer.  Every one of them forced in turn (HM_OPT_CONV_TILE) on exact-integer data -- 3x3 stride 1 and 2, 1x1, ragged
+    M (not a multiple of any tile), Cout below and above the tile width, strided input and output slices -- must give the
+    exact result, and on random data bit for bit what the default choice gives (same K order in every tile)."""
+    with L.option(L.HM_OPT_CONV_TILE, tile):
+        for (Ci, Co, k, s, H, W) in ((16, 32, 3, 1, 9, 11), (32, 264, 3, 2, 21, 19), (64, 72, 1, 1, 33, 35), (8, 256, 3, 1, 30, 34)):
+            x = (torch.arange(2 * Ci * H * W).reshape(2, Ci, H, W) % 5 - 2).float()
+            w = ((torch.arange(Co * Ci * k * k).reshape(Co, Ci, k, k) * 7 + torch.arange(Co)[:, None, None, None]) % 3 - 1).float()
+            b = (torch.arange(Co) % 7 - 3).float()
+            ref = F.conv2d(x, w, b, stride=s, padding=k // 2)
+            assert torch.equal(_conv_gpu(x, w, b, k, s, act=False, dt=torch.float16, out_f32=True), ref), (tile, Ci, Co, k, s)
+            y = _conv_gpu(x, w, b, k, s, act=False, dt=torch.float16, ld_extra=8, y_extra=8)       # 16-bit store path, strided slices
+            assert torch.equal(y, ref.half().float()), (tile, Ci, Co, k, s)
+    x = synth.uniform("tx", (2, 128, 24, 40), 1.0, seed=3).half().float()
+    w = synth.uniform("tw", (256, 128, 3, 3), 0.05, seed=4).half().float()
+    b = synth.uniform("tb", (256,), 0.3, seed=5)
+    base = _conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16)
+    with L.option(L.HM_OPT_CONV_TILE, tile):
+        assert torch.equal(_conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16), base)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_conv_split_k_exact_and_close(dt):
+    """Split-K convolution (hm_conv_args.splitk_ws: few output tiles, long K -- the 12x20 / 24x40 maps of the YOLOv7 neck):
+    fp32 partial slabs per K range, added in order by the reduce kernel, then bias + SiLU.  Exact on integer data for 2, 4 and
+    8 ranges and for the automatic choice; on random data within fp32 summation-order distance of the unsplit kernel; a
+    workspace too small for the wanted ranges falls back to fewer (or none), never past its end."""
+    Ci, Co, H, W = 256, 256, 12, 20                                   # K = 2304 = 36 K tiles; 2 x 240 rows -> 4 x 1 tiles of 128 x 256
+    x = (torch.arange(2 * Ci * H * W).reshape(2, Ci, H, W) % 5 - 2).float()
+    w = ((torch.arange(Co * Ci * 9).reshape(Co, Ci, 3, 3) * 7 + torch.arange(Co)[:, None, None, None]) % 3 - 1).float()
+    b = (torch.arange(Co) % 7 - 3).float()
+    ref = F.conv2d(x, w, b, stride=1, padding=1)
+    ws = torch.full((8 * 2 * H * W * Co * 4 + 64,), 0xAB, dtype=torch.uint8, device=DEV)
+    for ranges in (0, 2, 4, 8):
+        with L.option(L.HM_OPT_CONV_SPLITK, ranges):
+            y = _conv_gpu(x, w, b, 3, 1, act=False, dt=dt, ld_extra=8, y_extra=8, splitk_ws=ws[:-64])
+        assert torch.equal(y, ref.to(dt).float()), ranges
+        assert bool((ws[-64:] == 0xAB).all())                        # nothing written past the workspace
+    tiny = torch.empty(2 * H * W * Co * 4 * 2, dtype=torch.uint8, device=DEV)      # room for two slabs only
+    with L.option(L.HM_OPT_CONV_SPLITK, 8):
+        assert torch.equal(_conv_gpu(x, w, b, 3, 1, act=False, dt=dt, splitk_ws=tiny), ref.to(dt).float())
+    xr = synth.uniform("sx", (2, Ci, H, W), 1.0, seed=1).to(dt).float()
+    wr = synth.uniform("sw", (Co, Ci, 3, 3), 0.03, seed=2).to(dt).float()
+    br = synth.uniform("sb", (Co,), 0.3, seed=3)
+    one = _conv_gpu(xr, wr, br, 3, 1, act=True, dt=dt)
+    with L.option(L.HM_OPT_CONV_SPLITK, 4):
+        four = _conv_gpu(xr, wr, br, 3, 1, act=True, dt=dt, splitk_ws=ws[:-64])
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    np.testing.assert_allclose(four.numpy(), one.numpy(), atol=1e-4, rtol=2 * ulp)     # one 16-bit ulp: the fp32 sums differ in the last bits
+
+
+def test_yolo_pair_fusion_and_split_k_do_not_change_the_network():
+    """E-ELAN cv1 / cv2 (two 1x1 convolutions of one input, adjacent slices of the block's Concat) run as one launch with
+    stacked weight rows: every output channel is the same dot product in the same K order, so every layer output of the
+    network must be bit-identical with and without the fusion.  Split-K changes the fp32 summation order of the split layers
+    only: the head's raw logits stay within the fp16 reordering noise of the unsplit run."""
+    sd = synth.yolo_state_dict(seed=0, nc=3)
+    frame = synth.frame_u8(384, 640, seed=5).to(DEV)
+    outs = {}
+    for name, fuse_pairs, split in (("plain", False, False), ("fused", True, False), ("fused_split", True, True)):
+        e = YoloEngine(sd, nc=3, device=DEV)
+        e.fuse_pairs, e.split_k = fuse_pairs, split
+        p = e.forward(frame)
+        torch.cuda.synchronize()
+        outs[name] = ([e.layer_output(p, i) for i in (4, 5, 11, 24, 37, 50, 63, 75, 88, 101)], [r[0].clone().cpu() for r in p["raws"]], p["n_ops"])
+    assert outs["fused"][2] == outs["plain"][2] - 8                  # eight E-ELAN blocks
+    for a, b_ in zip(outs["plain"][0], outs["fused"][0]):
+        assert torch.equal(a, b_)
+    for a, b_ in zip(outs["plain"][1], outs["fused"][1]):
+        assert torch.equal(a, b_)
+    for a, b_ in zip(outs["plain"][1], outs["fused_split"][1]):
+        assert float((a - b_).abs().max()) < 0.15 and float((a - b_).abs().mean()) < 5e-3        # measured 0.07 max / 2.1e-3 mean on logits of |x| ~ 1
 
 
 def test_maxpool_and_upsample():
