@@ -201,12 +201,22 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
       int Mi = B * T;
       HM_TRY(hm_layernorm(xc, b.ln1_g, b.ln1_b, h, dt, Mi, D, w->vit_eps, stream));
       HM_TRY(gemm_m(Mi, h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
+      const int rr = w->tome_r[i] < T / 2 ? w->tome_r[i] : T / 2;
+      // matching metric in fp32 (k.mean(heads) is linear in LN1(x)): fp32 LayerNorm output into the spare residual buffer (free
+      // until this block's merge writes it), then one small fp32 linear; must read x BEFORE proj updates it
+      if (b.kmean_w && rr > 0) {
+        HM_TRY(hm_layernorm(xc, b.ln1_g, b.ln1_b, xn, HM_OUT_F32, Mi, D, w->vit_eps, stream));
+        HM_TRY(hm_linear_f32(xn, D, b.kmean_w, D, b.kmean_b, nullptr, 0, (float*)(ws + L.tmetric), D / w->heads, Mi, D / w->heads, D, 0, stream));
+      }
       HM_TRY(hm_tome_attention(qkv, szc, att, B, T, w->heads, D / w->heads, scale, dt, stream));
       HM_TRY(resid_m(Mi, att, D, b.proj_w, b.proj_b, xc, b.ln2_g, b.ln2_b));
       int r = w->tome_r[i] < T / 2 ? w->tome_r[i] : T / 2;          // r = min(r, t // 2) (:42)
       if (r > 0) {
-        HM_TRY(hm_tome_merge(qkv, xc, szc, xn, szn, (float*)(ws + L.tmetric), (int*)(ws + L.tindex), B, T, r, w->heads,
-                             D / w->heads, D, dt, stream));
+        if (b.kmean_w)
+          HM_TRY(hm_tome_merge_metric((const float*)(ws + L.tmetric), D / w->heads, 0, xc, szc, xn, szn, (int*)(ws + L.tindex), B, T, r, D, stream));
+        else
+          HM_TRY(hm_tome_merge(qkv, xc, szc, xn, szn, (float*)(ws + L.tmetric), (int*)(ws + L.tindex), B, T, r, w->heads,
+                               D / w->heads, D, dt, stream));
         float* t0 = xc; xc = xn; xn = t0;
         float* s_old = szc;
         szc = szn;

@@ -2005,16 +2005,22 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
   *(typename T::vec8*)(y + (size_t)m * ldy + n) = o;
 }
 
-// K ranges for a convolution: only when the best tile leaves most of the chip idle and K is long; whole 64-deep K tiles per range
-int pick_conv_split(const KArgs& g, int tile, size_t ws_bytes) {
+// K ranges for a convolution.  The choice depends on the PER-IMAGE problem only (output pixels of one image, Cout, K) -- never on
+// the number of images in the batch -- so a frame gives bit-identical results whether it runs alone or in a batched pass
+// (split-K changes the fp32 summation order; a different order per batch size would move fp16 roundings and, through them,
+// boxes by a pixel).  The rule is a compromise between one frame (few tiles: every serial K-step costs ~0.8 us of exposed
+// latency, partial slabs are tiny) and sixteen (slab traffic 2 x ranges x M x N x 4 bytes counts):
+//   12x20-sized maps (<= 256 pixels):  K >= 2048 -> 4 ranges, K >= 1024 -> 2
+//   24x40-sized maps (<= 1024 pixels): K >= 2048 and Cout <= 256 -> 2
+int conv_split_rule(const KArgs& g) {
   const int forced = hm_option(HM_OPT_CONV_SPLITK);
-  const int tiles = conv_tiles(g, tile), nk = g.K / 64;
-  if (forced == 1 || g.N % 8 != 0 || (g.ldc & 7) != 0 || tiles > 128 || nk < 8) return 1;
-  int want = forced > 1 ? forced : 256 / tiles;
-  if (want > 8) want = 8;
+  const int m_img = g.Hout * g.Wout, nk = g.K / 64;
+  if (forced == 1 || g.N % 8 != 0 || (g.ldc & 7) != 0 || nk < 8) return 1;
+  int want = 1;
+  if (forced > 1) want = forced;
+  else if (m_img <= 256) want = nk >= 32 ? 4 : (nk >= 16 ? 2 : 1);
+  else if (m_img <= 1024) want = (nk >= 32 && g.N <= 256) ? 2 : 1;
   if (want > nk / 4) want = nk / 4;                        // at least 4 K tiles per range: the ring's start-up is two tiles
-  while (want > 1 && nk % want != 0) --want;
-  while (want > 1 && (size_t)want * g.M * g.N * 4 > ws_bytes) --want;
   while (want > 1 && nk % want != 0) --want;
   return want < 1 ? 1 : want;
 }
@@ -2023,7 +2029,9 @@ template <class T>
 int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStream_t s) {
   KArgs g = g0;
   const bool act_ok = epilogue == HM_EPI_STORE || epilogue == HM_EPI_SILU || epilogue == HM_EPI_RELU;
-  const int ks = (ws && g.bias && act_ok && (((uintptr_t)ws) & 15) == 0) ? pick_conv_split(g, pick_conv_tile(g), ws_bytes) : 1;
+  int ks = (ws && g.bias && act_ok && (((uintptr_t)ws) & 15) == 0) ? conv_split_rule(g) : 1;
+  if (ks > 1 && (size_t)ks * g.M * g.N * 4 > ws_bytes)
+    return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: splitk_ws too small (hm_conv_splitk_bytes gives the size; the split must not depend on what fits)");
   const int t = pick_conv_tile(g, ks);
   if (ks > 1) {
     void* y = g.C; const int ldy = g.ldc; const float* bias = g.bias;
@@ -2146,6 +2154,16 @@ extern "C" int hm_gemm_fp8(const hm_gemm_fp8_args* a, void* stream_) {
       return launch_fp8<HM_EPI_GELU_MX8>(k, stream);
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm_fp8: epilogue must be STORE, RESID_F32 or GELU_MX8");
   }
+}
+
+extern "C" size_t hm_conv_splitk_bytes(const hm_conv_args* a) {
+  if (!a || a->out_f32 || a->resid || !a->bias || a->ksize <= 0 || a->stride <= 0 || a->Kpad % 64 != 0) return 0;
+  const int pad = a->ksize / 2;
+  KArgs k{};
+  k.Hout = (a->H + 2 * pad - a->ksize) / a->stride + 1; k.Wout = (a->W_in + 2 * pad - a->ksize) / a->stride + 1;
+  k.M = a->N * k.Hout * k.Wout; k.N = a->Cout; k.K = a->Kpad; k.ldc = a->ldy;
+  const int ks = conv_split_rule(k);
+  return ks > 1 ? (size_t)ks * k.M * k.N * 4 : 0;
 }
 
 extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {

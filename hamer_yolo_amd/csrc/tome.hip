@@ -99,18 +99,23 @@ __global__ __launch_bounds__(256) void tome_metric_kernel(const E* __restrict__ 
 }
 
 // idx layout per crop: [3][TM_MAXT / 2] ints = unm_idx | src_idx | dst_idx
-__global__ __launch_bounds__(128) void tome_match_kernel(const float* __restrict__ metric, int* __restrict__ idx, int T, int r) {
+__global__ __launch_bounds__(128) void tome_match_kernel(const float* __restrict__ metric, int* __restrict__ idx, int T, int r,
+                                                         int ld, int lo_off) {
   __shared__ float m[TM_MAXT * (TM_HD + 1)];
   __shared__ float nmax[TM_MAXT / 2];
   __shared__ int nidx[TM_MAXT / 2];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int Na = (T + 1) / 2, Nb = T / 2;
-  const float* mb = metric + (size_t)b * T * TM_HD;
+  const float* mb = metric + (size_t)b * T * ld;                    // row stride ld; lo_off > 0: value = hi + lo (columns d and lo_off + d)
   for (int t = tid; t < T; t += 128) {                              // metric / metric.norm(dim=-1) (:47)
     float ss = 0.f;
-    for (int d = 0; d < TM_HD; ++d) { const float v = mb[t * TM_HD + d]; ss = fmaf(v, v, ss); }
+    for (int d = 0; d < TM_HD; ++d) {
+      const float v = lo_off ? mb[(size_t)t * ld + d] + mb[(size_t)t * ld + lo_off + d] : mb[(size_t)t * ld + d];
+      m[t * (TM_HD + 1) + d] = v;
+      ss = fmaf(v, v, ss);
+    }
     const float n = sqrtf(ss);
-    for (int d = 0; d < TM_HD; ++d) m[t * (TM_HD + 1) + d] = mb[t * TM_HD + d] / n;
+    for (int d = 0; d < TM_HD; ++d) m[t * (TM_HD + 1) + d] /= n;
   }
   __syncthreads();
   for (int a = tid; a < Na; a += 128) {                             // scores = a @ b^T; node_max, node_idx = scores.max(-1)
@@ -205,7 +210,19 @@ extern "C" int hm_tome_merge(const void* qkv, const float* x, const float* size,
   else if (dtype == HM_DTYPE_F16)
     hipLaunchKernelGGL(tome_metric_kernel<_Float16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const _Float16*)qkv, metric_ws, B * tokens, heads);
   else return hm_set_error(HM_ERR_ARG, "hm_tome_merge: bad dtype");
-  hipLaunchKernelGGL(tome_match_kernel, dim3(B), dim3(128), 0, s, metric_ws, index_ws, tokens, r);
+  hipLaunchKernelGGL(tome_match_kernel, dim3(B), dim3(128), 0, s, metric_ws, index_ws, tokens, r, TM_HD, 0);
   hipLaunchKernelGGL(tome_merge_kernel, dim3(B * (tokens - r)), dim3(256), 0, s, x, size, index_ws, x_out, size_out, tokens, r, D);
   return hm_check_launch("hm_tome_merge");
+}
+
+extern "C" int hm_tome_merge_metric(const float* metric, int ld_metric, int lo_off, const float* x, const float* size, float* x_out,
+                                    float* size_out, int* index_ws, int B, int tokens, int r, int D, void* stream_) {
+  if (!metric || !x || !x_out || !size_out || !index_ws || B <= 0) return hm_set_error(HM_ERR_ARG, "hm_tome_merge_metric: null pointer");
+  if (tokens <= 1 || tokens > TM_MAXT || D <= 0 || r <= 0 || r > tokens / 2 || ld_metric < TM_HD || lo_off < 0 || (lo_off && lo_off + TM_HD > ld_metric))
+    return hm_set_error(HM_ERR_ARG, "hm_tome_merge_metric: 1 < tokens <= 192, 0 < r <= tokens / 2, metric rows of >= 80 (+ lo part) floats");
+  hipStream_t s = (hipStream_t)stream_;
+  HmProfScope prof(HM_K_OTHER, 6, B, tokens, r, s);
+  hipLaunchKernelGGL(tome_match_kernel, dim3(B), dim3(128), 0, s, metric, index_ws, tokens, r, ld_metric, lo_off);
+  hipLaunchKernelGGL(tome_merge_kernel, dim3(B * (tokens - r)), dim3(256), 0, s, x, size, index_ws, x_out, size_out, tokens, r, D);
+  return hm_check_launch("hm_tome_merge_metric");
 }

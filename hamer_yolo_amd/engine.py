@@ -120,6 +120,11 @@ class HamerEngine:
                     wpad = torch.zeros(D, v.heads, 96, device=self.device)
                     wpad[:, :, :80] = wp.reshape(D, v.heads, 80)
                     b.proj_w8, b.proj_ws = w8(wpad.reshape(D, v.heads * 96))
+            if token_merge and v.head_dim == 80 and not self.fp8:
+                # matching metric of ToMe in fp32 (hm_vit_block.kmean_w): mean over heads of the key rows and biases
+                wk = sd[p + "attn.qkv.weight"].detach().to(self.device, torch.float64)[D:2 * D].reshape(v.heads, v.head_dim, D).mean(0)
+                bk = sd[p + "attn.qkv.bias"].detach().to(self.device, torch.float64)[D:2 * D].reshape(v.heads, v.head_dim).mean(0)
+                b.kmean_w, b.kmean_b = L.ptr(f32(wk.float())), L.ptr(f32(bk.float()))
             if self.fold_ln:
                 cs, bl = ln_fold(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], sd[p + "norm1.weight"], sd[p + "norm1.bias"])
                 b.qkv_colsum, b.qkv_bias_ln = L.ptr(cs), L.ptr(bl)

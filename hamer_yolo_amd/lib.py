@@ -25,7 +25,7 @@ EXPORTS = [
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
-    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option",
+    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -65,7 +65,7 @@ class VitBlock(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "proj_w", "fc1_w", "fc2_w",
                                   "qkv_b", "proj_b", "fc1_b", "fc2_b",
                                   "qkv_colsum", "qkv_bias_ln", "fc1_colsum", "fc1_bias_ln",
-                                  "qkv_w8", "fc1_w8", "fc2_w8", "qkv_ws", "fc1_ws", "fc2_ws", "proj_w8", "proj_ws")]
+                                  "qkv_w8", "fc1_w8", "fc2_w8", "qkv_ws", "fc1_ws", "fc2_ws", "proj_w8", "proj_ws", "kmean_w", "kmean_b")]
 
 
 class DecLayer(C.Structure):
@@ -147,6 +147,8 @@ def load() -> C.CDLL:
     lib.hm_gap_linear.argtypes = [vp, i, i, vp, C.c_float, vp, vp, i, i, vp]
     lib.hm_layernorm_accum.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, C.c_float, vp]
     lib.hm_conv2d_nhwc.argtypes = [C.POINTER(ConvArgs), vp]
+    lib.hm_conv_splitk_bytes.argtypes = [C.POINTER(ConvArgs)]
+    lib.hm_conv_splitk_bytes.restype = C.c_size_t
     lib.hm_maxpool_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.hm_upsample2x_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]
     lib.hm_letterbox_plan_make.argtypes = [i, i, i, i, C.POINTER(LetterboxPlan)]
@@ -161,6 +163,7 @@ def load() -> C.CDLL:
     lib.hm_tome_index_bytes.restype = C.c_size_t
     lib.hm_tome_attention.argtypes = [vp, vp, vp, i, i, i, i, f, i, vp]
     lib.hm_tome_merge.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
+    lib.hm_tome_merge_metric.argtypes = [vp, i, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
     lib.hm_gemm_set_variant.argtypes = [i]
     lib.hm_gemm_set_group_m.argtypes = [i]
     lib.hm_set_option.argtypes = [i, i]
@@ -172,7 +175,7 @@ def load() -> C.CDLL:
         if not hasattr(lib, name):
             raise HipLibraryError(f"{LIB_PATH} does not export {name}")
         fn = getattr(lib, name)
-        if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes", "hm_nms_workspace_bytes", "hm_tome_index_bytes"):
+        if name not in ("hm_version", "hm_last_error_string", "hm_hamer_workspace_bytes", "hm_nms_workspace_bytes", "hm_tome_index_bytes", "hm_conv_splitk_bytes"):
             fn.restype = i
     if lib.hm_version() != HM_VERSION:
         raise HipLibraryError(f"{LIB_PATH} reports HM_VERSION {lib.hm_version()}, this binding is written for {HM_VERSION}: "

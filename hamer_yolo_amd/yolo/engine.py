@@ -133,13 +133,6 @@ class YoloEngine:
         arena = torch.zeros(total, dtype=torch.uint8, device=self.device)
         base = arena.data_ptr()
         esz = 2
-        # split-K scratch (hm_conv_args.splitk_ws): shared by all layers of the plan, sized for 8 fp32 slabs of the largest output
-        # among the layers small enough to be split (<= 128 tiles of 128 x 128), capped at 128 MB; the library uses what fits
-        small = [nb * hw[i][0] * hw[i][1] * ch[i] for i, (_, kind, _a) in enumerate(layers)
-                 if kind in ("conv", "repconv", "sppcspc") and nb * hw[i][0] * hw[i][1] * ch[i] <= 128 * 128 * 128]
-        ws_bytes = min(128 << 20, 8 * 4 * max(small)) if (small and self.split_k) else 0
-        splitk_ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.device)
-        ws_ptr = splitk_ws.data_ptr() if ws_bytes else None
 
         def addr(buf, ch_off=0):
             return base + offs[buf] + ch_off * esz
@@ -156,7 +149,7 @@ class YoloEngine:
 
         def emit_conv(wt, bs, cin, k, s, co, xptr, ldx, h, w, yptr, ldy, act, out_f32):
             a = L.ConvArgs(xptr, wt.data_ptr(), yptr, bs.data_ptr(), self.zeros.data_ptr(), nb, h, w, cin, co, k, s, ldx, ldy,
-                           wt.shape[1], act, out_f32, self.dt, None, 0, ws_ptr, ws_bytes)
+                           wt.shape[1], act, out_f32, self.dt, None, 0, None, 0)
             ops.append(L.YoloOp(0, 0, a))
 
         def flush():
@@ -232,6 +225,14 @@ class YoloEngine:
                     raws.append((raw, hh, ww))
                     conv(f"model.{i}.m.{l}", xp, ldxx, hh, ww, raw.data_ptr(), 3 * self.no, act=0, out_f32=1)
         flush()
+        # split-K scratch (hm_conv_args.splitk_ws), shared by the plan's layers (they run one after another): the library says
+        # how much each convolution needs (its rule looks at one image's output, so results do not depend on nb)
+        ws_bytes = max([self.lib.hm_conv_splitk_bytes(C.byref(op.conv)) for op in ops if op.kind == 0] + [0]) if self.split_k else 0
+        splitk_ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.device)
+        if ws_bytes:
+            for op in ops:
+                if op.kind == 0:
+                    op.conv.splitk_ws, op.conv.splitk_ws_bytes = splitk_ws.data_ptr(), ws_bytes
         op_arr = (L.YoloOp * len(ops))(*ops)
         n_pred = sum(3 * hh * ww for _, hh, ww in raws)
         plan = {

@@ -148,6 +148,10 @@ int hm_tome_attention(const void* qkv, const float* size, void* out, int B, int 
                       int dtype, void* stream);
 int hm_tome_merge(const void* qkv, const float* x, const float* size, float* x_out, float* size_out, float* metric_ws,
                   int* index_ws, int B, int tokens, int r, int heads, int head_dim, int D, int dtype, void* stream);
+/* hm_tome_merge with a caller-supplied fp32 metric: metric[(b*tokens + t) * ld_metric + d] (+ the same at column lo_off + d when
+ * lo_off > 0: a hi / lo pair), d < 80. */
+int hm_tome_merge_metric(const float* metric, int ld_metric, int lo_off, const float* x, const float* size, float* x_out,
+                         float* size_out, int* index_ws, int B, int tokens, int r, int D, void* stream);
 
 /* Same attention with MXFP8 output for an fp8 proj GEMM (bf16 qkv in).  Heads are widened from 80 to 96 columns so that
  * scale blocks of 32 never straddle two heads: out8 [B*tokens][heads*96] e4m3 bytes (columns 80..95 of every head zero),
@@ -232,6 +236,13 @@ typedef struct hm_vit_block {
    * for d < 80 and zero for d >= 80 (the K order of hm_vit_attention_mx8), proj_ws its per-output-channel scale. */
   const void* proj_w8;
   const float* proj_ws;
+  /* optional, token merging only (round 3): the matching metric k.mean(heads) = LN1(x) . Wbar^T + bbar with
+   * Wbar = mean over heads of the key rows of qkv.weight (the metric is linear in the keys, selective_vit_adapter.py:198), so
+   * hm_hamer_forward forms it entirely in fp32 -- an fp32 LayerNorm output and hm_linear_f32 -- instead of averaging 16-bit
+   * keys: merge decisions then follow the fp32 reference up to what the residual stream itself differs by.
+   * kmean_w: f32 [80][embed_dim]; kmean_b: f32 [80]. */
+  const float* kmean_w;
+  const float* kmean_b;
 } hm_vit_block;
 
 typedef struct hm_dec_layer {
@@ -305,9 +316,10 @@ typedef struct hm_conv_args {
   int dtype;
   const void* resid;  /* optional with act == 2: [N][Hout][Wout][ldr] 16-bit added before the ReLU (BasicBlock identity) */
   int ldr;
-  /* round 3, optional: scratch for split-K (few output tiles, long K: the small maps of the YOLOv7 neck).  When given (16-byte
-   * aligned), the library may cut K into up to 8 ranges that write fp32 partial slabs [ranges][N*Hout*Wout][Cout] here and add
-   * them, in order, in a second small kernel; 8 * N*Hout*Wout * Cout * 4 bytes always suffice, less is used as it fits. */
+  /* round 3, optional: scratch for split-K (few output tiles, long K: the 12x20 / 24x40 maps of the YOLOv7 neck).  When given
+   * (16-byte aligned, at least hm_conv_splitk_bytes(args) bytes), the library cuts K into 2 or 4 ranges by a rule that looks at
+   * ONE image's output only (so a frame's result does not depend on the batch it rides in), writes fp32 partial slabs
+   * [ranges][N*Hout*Wout][Cout] here and adds them, in order, in a second small kernel. */
   void* splitk_ws;
   size_t splitk_ws_bytes;
 } hm_conv_args;
@@ -315,6 +327,8 @@ typedef struct hm_conv_args {
 /* Conv2d(k in {1,3,5,7}, stride in {1,2}, pad k/2) + bias (+ SiLU / ReLU / residual add + ReLU) as an implicit GEMM on MFMA.
  * Cin must be a power of two >= 8 (the 3-channel image is stored with 8 channels). */
 int hm_conv2d_nhwc(const hm_conv_args* args, void* stream);
+/* bytes of splitk_ws this convolution would use (0: it is never split) */
+size_t hm_conv_splitk_bytes(const hm_conv_args* args);
 
 /* nn.MaxPool2d(k, stride, pad) on NHWC 16-bit (MP common.py:34-40: k=2,s=2; SPPCSPC common.py:275:
  * k=5/9/13, s=1, pad k/2 -- the 9 and 13 windows are cascades of the 5 window). C % 8 == 0. */

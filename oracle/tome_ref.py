@@ -77,7 +77,15 @@ def tome_attention(sd, h: Tensor, p: str, vit, size, emu=False) -> Tuple[Tensor,
         attn = attn + size.log()[:, None, None, :, 0]
     attn = attn.softmax(dim=-1)
     o = _q((attn @ v).transpose(1, 2).reshape(B, N, C), emu)
-    return _linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], emu), k.mean(1)
+    metric = k.mean(1)                                   # the reference: head-averaged keys (:198)
+    if emu:
+        # the kernels' arithmetic (round 3): k.mean(heads) is linear in h, so the build forms the metric entirely in fp32 (an
+        # fp32 LayerNorm output, the fp32 head-mean of the key weights) instead of averaging 16-bit keys -- i.e. exactly the
+        # reference's expression above evaluated on unquantised operands
+        D = vit.embed_dim
+        k32 = F.linear(h, sd[p + "attn.qkv.weight"][D:2 * D], sd[p + "attn.qkv.bias"][D:2 * D])
+        metric = k32.reshape(B, N, vit.heads, -1).mean(2)
+    return _linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], emu), metric
 
 
 def vit_forward_tome(sd, x: Tensor, vit, r=(8, -1), emu=False, prefix="backbone.", trace: Dict = None) -> Tensor:

@@ -265,9 +265,49 @@ def test_tome_forward_vs_oracle_and_reference_golden(golden_dir, dtype):
     _report(f"tome_forward[{emu}]", crops_that_are_permutations=perm_crops, tokens_set_distance_vs_emu=d_set, pose6d_vs_emu=d_pose,
             pose6d_vs_reference_fp32=g_pose)
     if dtype == torch.float16:
-        assert perm_crops >= 2 and d_set < 5e-2 and d_pose < 5e-3
+        # round 3 (matching metric formed in fp32 from the fp32 LayerNorm output): every crop is an exact permutation of the
+        # oracle's token set and the regressed pose agrees to fp32 noise (measured 3 / 3, 7.9e-6)
+        assert perm_crops == 3 and d_set < 5e-2 and d_pose < 2e-4
     assert d_pose < 1e-2 and g_pose < 1e-2
     assert torch.isfinite(out["pred_vertices"]).all()
+
+
+def test_tome_vith_geometry_vs_oracle_nondegenerate_schedule():
+    """ToMe at the ViT-H geometry against the oracle with a schedule that keeps a usable sequence: r = 8 for the first 8 blocks,
+    then none (192 -> 128 tokens; the reference's own (8, -1) collapses ViT-H to one token, next test).  Round 3: the matching
+    metric is formed in fp32 from the LayerNorm output (hm_vit_block.kmean_w), so merge decisions track the fp32 reference;
+    compared with the oracle in the kernels' arithmetic (token sets, regressed parameters) and with the fp32 oracle."""
+    from oracle import tome_ref as T
+    cfg = synth.HamerConfig()
+    sd = synth.hamer_state_dict(cfg, seed=0)
+    mp = synth.mano_params(seed=0)
+    sched = [8] * 8 + [0] * 24
+    eng = HamerEngine(sd, mp, cfg, token_merge=sched)
+    assert eng.ctx_tokens == 128
+    img = synth.normalize_crops(synth.crops_u8(2, seed0=40))
+    out = eng.forward(img.cuda(), want_tokens=True)
+    torch.cuda.synchronize()
+    tok = out["tokens"].float().cpu()[:2 * 128].reshape(2, 128, -1)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        feats = T.vit_forward_tome(sd, img[:, :, :, 32:-32], cfg.vit, sched, emu="fp16")
+        pose, betas, cam = R.mano_head_forward(sd, R._q(feats, "fp16"), cfg.dec, "fp16")
+        feats32 = T.vit_forward_tome(sd, img[:, :, :, 32:-32], cfg.vit, sched, emu=False)
+        pose32, betas32, _ = R.mano_head_forward(sd, feats32, cfg.dec, False)
+    perm = 0
+    for b in range(2):
+        nn = torch.cdist(tok[b], feats[b]).argmin(1)
+        perm += int(sorted(nn.tolist()) == list(range(128)))
+    d_emu = float((out["pose6d"].cpu() - pose).abs().max())
+    d_32 = float((out["pose6d"].cpu() - pose32).abs().max())
+    d_b32 = float((out["betas"].cpu() - betas32).abs().max())
+    _report("tome_vith_r8x8", crops_that_are_permutations=perm, pose6d_vs_emu=d_emu, pose6d_vs_fp32_oracle=d_32, betas_vs_fp32_oracle=d_b32)
+    assert torch.isfinite(out["pred_vertices"]).all()
+    # measured (round 3): 1.3e-2 vs the oracle in the kernels' arithmetic, 2.2e-2 vs the fp32 oracle, no crop an exact
+    # permutation: 8 blocks x 96 proposals ranked per crop leave near-ties that last-bit differences of the fp32 residual stream
+    # (accumulation order of the 16-bit GEMMs) resolve differently, and with random-init weights ONE flipped merge moves the
+    # regressed pose by ~1e-2.  On the 6-block geometry the same code tracks its oracle to 8e-6 (test above).
+    assert d_emu < 5e-2 and d_32 < 5e-2 and d_b32 < 5e-2
 
 
 def test_tome_vith_schedule_runs_to_one_token():
