@@ -1128,7 +1128,7 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 //   guarantees M, N multiples of 256), issued after the copies W(t+1), X(t+2) of the last step; the first step of the next
 //   tile therefore waits vmcnt(16 + 4): everything but those stores and X(t+2).  An extra vector-memory operation
 //   anywhere (a spill, the next tile's bias request) only makes a counted wait stricter, never looser.
-template <class T, int EPI>
+template <class T, int EPI, bool DIRECT = true>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
@@ -1266,6 +1266,47 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     char* wl = smem + XRING + xs_last * TILE_BYTES + wave * 4096;
     const int arow = lane & 15, apiece = lane >> 4, row0 = lane >> 2, j = lane & 3;
     const int mb = m0 + wr * 64, nb = n0 + wc * 128;
+    if constexpr (DIRECT) {
+      // Round 3: no LDS round trip.  A lane holds C[row li][4 columns] of each 16 x 16 accumulator tile -- 8 bytes of 16-bit
+      // output, 32-byte runs per row if stored as is.  For a PAIR of neighbouring column tiles (ni, ni + 1) one
+      // v_permlane16_swap per register (rows 1 / 3 of the first operand <-> rows 0 / 2 of the second; row = 16 lanes)
+      // leaves every lane with 8 CONSECUTIVE columns: lane group g holds columns [8 (g >> 1), + 8) of tile ni + (g & 1), so one
+      // 16-byte store per lane writes 64 contiguous bytes of each of 16 rows -- the same store shape as the staged epilogue,
+      // the same 16 stores per wave (the counted waits do not change), the same arithmetic per value (bit-identical
+      // results), and none of its 32 + 32 LDS instructions per wave.
+      const int g4 = lane >> 4;
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      f32x4_t bv[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bv[ni] = *(const f32x4_t*)(cb + ni * 16 + 4 * g4);
+      elem* crow = (elem*)g.C + (size_t)(mb + arow) * g.ldc + nb + (g4 & 1) * 16 + (g4 >> 1) * 8;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int np = 0; np < NI / 2; ++np) {
+          unsigned pk[2][2];                                         // [tile of the pair][dword]: 4 x 16-bit values
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4_t a = acc[2 * np + h][mi], bb = bv[2 * np + h];
+            float v0 = __fadd_rn(a[0], bb[0]), v1 = __fadd_rn(a[1], bb[1]), v2 = __fadd_rn(a[2], bb[2]), v3 = __fadd_rn(a[3], bb[3]);
+            if constexpr (EPI == HM_EPI_GELU) {
+              // (pairs as the staged epilogue forms them: values q and 4 + q of a lane's 8 columns -- there columns c, c + 4;
+              //  gelu_fast2 evaluates its two values independently, so the pairing does not change a result)
+              const f32x2_t g0 = gelu_fast2(f32x2_t{v0, v1}), g1 = gelu_fast2(f32x2_t{v2, v3});
+              v0 = g0[0]; v1 = g0[1]; v2 = g1[0]; v3 = g1[1];
+            }
+            typename T::vec4 o;
+            o[0] = (elem)v0; o[1] = (elem)v1; o[2] = (elem)v2; o[3] = (elem)v3;
+            const u32x2 w = __builtin_bit_cast(u32x2, o);
+            pk[h][0] = w[0]; pk[h][1] = w[1];
+          }
+          const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          *(u32x4*)(crow + (size_t)(mi * 16) * g.ldc + np * 32) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+      continue;
+    }
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) {
       const f32x4_t b0 = *(const f32x4_t*)(cb + cg * 32 + 8 * j), b1 = *(const f32x4_t*)(cb + cg * 32 + 8 * j + 4);
@@ -1300,9 +1341,15 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
 template <class T, int EPI>
 int launch_px(const KArgs& g, hipStream_t s) {
   constexpr int LDS = 5 * 256 * 128;
-  auto kern = gemm_px_kernel<T, EPI>;
-  static HmLdsOnce lds_once;
-  if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
+  // Epilogue form.  Both are bit-identical; measured in one process (profiles/r03_gemm_px_epilogue_ab.log): the lane-swap form
+  // is 3 % faster with the GELU (fc1 157.6 vs 162.1 us: its VALU work no longer queues behind 64 LDS instructions per wave)
+  // and 3 % slower for the plain store (qkv 119.8 vs 116.4, kv 177.2 vs 170.9) -- so each epilogue takes its faster form.
+  // HM_OPT_PX_LDS_EPILOGUE: 0 = that choice, 1 = always through LDS, 2 = always lane swaps.
+  const int form = hm_option(HM_OPT_PX_LDS_EPILOGUE);
+  const bool staged = form == 1 || (form == 0 && EPI != HM_EPI_GELU);
+  auto kern = staged ? gemm_px_kernel<T, EPI, false> : gemm_px_kernel<T, EPI, true>;
+  static HmLdsOnce lds_once[2];
+  if (const int rc = lds_once[staged ? 1 : 0].ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
   const int tiles = (g.M >> 8) * (g.N >> 8);
   int cus = hm_device_cu_count();
   if (cus <= 0) cus = 256;

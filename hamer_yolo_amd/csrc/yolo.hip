@@ -96,9 +96,11 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
 // ------------------------------------------------------------------------------- decode
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ raw, int ldraw, float* __restrict__ pred,
                                                      int row0, int ny, int nx, int no, float stride, float a0w, float a0h,
-                                                     float a1w, float a1h, float a2w, float a2h) {
+                                                     float a1w, float a1h, float a2w, float a2h, size_t raw_img, size_t pred_img) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= 3 * ny * nx) return;
+  raw += (size_t)blockIdx.y * raw_img;                  // image blockIdx.y of a batched pass (element strides between images)
+  pred += (size_t)blockIdx.y * pred_img;
   const int a = gid / (ny * nx), p = gid - a * ny * nx;
   const int y = p / nx, x = p - y * nx;
   const float aw = a == 0 ? a0w : (a == 1 ? a1w : a2w), ah = a == 0 ? a0h : (a == 1 ? a1h : a2h);
@@ -389,8 +391,20 @@ extern "C" int hm_yolo_decode(const float* raw, int ldraw, float* pred, int row0
   hipStream_t s = (hipStream_t)stream_;
   HmProfScope prof(HM_K_OTHER, 4, ny, nx, nc, s);
   hipLaunchKernelGGL(decode_kernel, dim3((3 * ny * nx + 255) / 256), dim3(256), 0, s, raw, ldraw, pred, row0, ny, nx, 5 + nc,
-                     stride, a[0], a[1], a[2], a[3], a[4], a[5]);
+                     stride, a[0], a[1], a[2], a[3], a[4], a[5], (size_t)0, (size_t)0);
   return hm_check_launch("hm_yolo_decode");
+}
+
+extern "C" int hm_yolo_decode_batch(const float* raw, int ldraw, float* pred, int row0, int ny, int nx, int nc, float stride,
+                                    const float* a, int nb, size_t pred_rows_per_image, void* stream_) {
+  if (!raw || !pred || !a || ny <= 0 || nx <= 0 || nc <= 0 || row0 < 0 || nb <= 0 || nb > 65535)
+    return hm_set_error(HM_ERR_ARG, "hm_yolo_decode_batch: bad arguments");
+  if (ldraw < 3 * (5 + nc)) return hm_set_error(HM_ERR_ARG, "hm_yolo_decode_batch: ldraw too small");
+  hipStream_t s = (hipStream_t)stream_;
+  HmProfScope prof(HM_K_OTHER, 4, ny, nx, nc, s);
+  hipLaunchKernelGGL(decode_kernel, dim3((3 * ny * nx + 255) / 256, nb), dim3(256), 0, s, raw, ldraw, pred, row0, ny, nx, 5 + nc,
+                     stride, a[0], a[1], a[2], a[3], a[4], a[5], (size_t)ny * nx * ldraw, pred_rows_per_image * (5 + nc));
+  return hm_check_launch("hm_yolo_decode_batch");
 }
 
 extern "C" size_t hm_nms_workspace_bytes(int n) {

@@ -118,9 +118,18 @@ class HAMER:
     def forward_step(self, batch: Dict, train: bool = False) -> Tuple[Dict, Dict]:
         if self._engine is None:
             raise HipLibraryError("call model.to('cuda') before the first forward")
-        x = batch["img"]
+        x = batch["img"].to(self.device, torch.float32)
         B = x.shape[0]
-        o = self._engine.forward(x.to(self.device, torch.float32), workspace=self._workspace(B))
+        # The 256-row GEMM tiles (persistent kernel, in-loop residual) need B * 192 rows to be a multiple of 256, i.e. B % 4 == 0;
+        # a chunk of frames yields whatever number of hands the detector found.  From 24 hands on (where those tiles are
+        # chosen) the batch is padded with copies of its last crop and the extra rows are dropped again: every hand is its own
+        # problem, so the real hands' results are what a batch of that size gives them.
+        Bp = (B + 3) // 4 * 4 if B >= 24 else B
+        if Bp != B:
+            x = torch.cat([x, x[-1:].expand(Bp - B, -1, -1, -1)], 0)
+        o = self._engine.forward(x, workspace=self._workspace(Bp))
+        if Bp != B:
+            o = {k: v[:B] for k, v in o.items()}
         R = o["rotmats"]
         pred_mano_params = {"global_orient": R[:, :1], "hand_pose": R[:, 1:], "betas": o["betas"]}
         output = {

@@ -17,7 +17,7 @@ HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 
 HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU, HM_EPI_GELU_MX8 = 5, 6, 7, 8
 HM_VERSION = 300      # include/hamer_hip.h: load() refuses a library built from another header
 (HM_OPT_PX_GRID, HM_OPT_FP8P_GRID, HM_OPT_FP8_ONE_TILE, HM_OPT_FP8P_RESID, HM_OPT_TOME_NO_SPLITK,
- HM_OPT_TOME_SCALAR_ATTENTION, HM_OPT_RESID_IN_EPILOGUE, HM_OPT_CONV_TILE, HM_OPT_CONV_SPLITK) = range(9)
+ HM_OPT_TOME_SCALAR_ATTENTION, HM_OPT_RESID_IN_EPILOGUE, HM_OPT_CONV_TILE, HM_OPT_CONV_SPLITK, HM_OPT_PX_LDS_EPILOGUE) = range(10)
 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
@@ -25,7 +25,7 @@ EXPORTS = [
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
-    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes",
+    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes", "hm_yolo_decode_batch",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -155,6 +155,7 @@ def load() -> C.CDLL:
     lib.hm_letterbox_tables.argtypes = [C.POINTER(LetterboxPlan), C.POINTER(C.c_int32)]
     lib.hm_letterbox.argtypes = [vp, C.POINTER(LetterboxPlan), vp, vp, i, vp, vp]
     lib.hm_yolo_decode.argtypes = [vp, i, vp, i, i, i, i, f, C.POINTER(C.c_float), vp]
+    lib.hm_yolo_decode_batch.argtypes = [vp, i, vp, i, i, i, i, f, C.POINTER(C.c_float), i, C.c_size_t, vp]
     lib.hm_nms_workspace_bytes.argtypes = [i]
     lib.hm_nms_workspace_bytes.restype = C.c_size_t
     lib.hm_yolo_nms.argtypes = [vp, i, i, f, f, C.c_uint, i, i, C.POINTER(LetterboxPlan), vp, vp, vp, C.c_size_t, vp]

@@ -278,13 +278,12 @@ class YoloEngine:
             self.letterbox(f.contiguous(), want_u8 and len(frames) == 1, p, i)
         st = L.current_stream()
         L.check(self.lib.hm_yolo_run(p["ops"], p["n_ops"], st), "hm_yolo_run")
-        for i in range(p["nb"]):
-            row0 = i * p["n_pred"]
-            for l, (raw, hh, ww) in enumerate(p["raws"]):
-                anc = (C.c_float * 6)(*self.anchors[l])
-                L.check(self.lib.hm_yolo_decode(raw.data_ptr() + i * hh * ww * 3 * self.no * 4, 3 * self.no, p["pred"].data_ptr(), row0,
-                                                hh, ww, self.nc, float(arch.STRIDES[l]), anc, st), "hm_yolo_decode")
-                row0 += 3 * hh * ww
+        row0 = 0
+        for l, (raw, hh, ww) in enumerate(p["raws"]):        # one decode launch per level for all images of the pass
+            anc = (C.c_float * 6)(*self.anchors[l])
+            L.check(self.lib.hm_yolo_decode_batch(raw.data_ptr(), 3 * self.no, p["pred"].data_ptr(), row0, hh, ww, self.nc,
+                                                  float(arch.STRIDES[l]), anc, p["nb"], p["n_pred"], st), "hm_yolo_decode_batch")
+            row0 += 3 * hh * ww
         return p
 
     def nms_enqueue(self, p: dict, conf_thres: float, iou_thres: float, classes: Optional[List[int]], agnostic: bool,

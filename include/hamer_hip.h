@@ -95,7 +95,8 @@ enum {
   HM_OPT_RESID_IN_EPILOGUE = 6,     /* 1: the fp32-residual GEMM fetches its residual rows in the epilogue (round-2 form) */
   HM_OPT_CONV_TILE = 7,             /* tuning: force convolution tile (1..9 = 128x128, 128x64, 128x32, 256x128, 256x256, 256x64, then the deep-ring 128x32, 128x64, 128x128); 0 = per-layer choice */
   HM_OPT_CONV_SPLITK = 8,           /* tuning: 1 = never split a convolution over K, n > 1 = ask for n ranges where splitting applies; 0 = automatic */
-  HM_OPT_COUNT = 9
+  HM_OPT_PX_LDS_EPILOGUE = 9,       /* persistent GEMM epilogue: 0 = per epilogue (GELU: lane swaps, store: through LDS), 1 = always LDS, 2 = always lane swaps */
+  HM_OPT_COUNT = 10
 };
 int hm_set_option(int key, int value);
 int hm_get_option(int key);
@@ -368,6 +369,10 @@ int hm_letterbox(const uint8_t* frame, const hm_letterbox_plan* plan, const int3
  * rows [row0 + a*ny*nx + y*nx + x][5+nc] of pred: sigmoid, xy = (2s-0.5+grid)*stride, wh = (2s)^2*anchor. */
 int hm_yolo_decode(const float* raw, int ldraw, float* pred, int row0, int ny, int nx, int nc, float stride,
                    const float* anchors6_host, void* stream);
+/* The same for `nb` images of one batched pass in one launch: image i's raw map starts ny*nx*ldraw floats after image i-1's,
+ * its rows of pred `pred_rows_per_image` rows after (round 3: 3 launches per pass instead of 3 per frame). */
+int hm_yolo_decode_batch(const float* raw, int ldraw, float* pred, int row0, int ny, int nx, int nc, float stride,
+                         const float* anchors, int nb, size_t pred_rows_per_image, void* stream);
 
 /* non_max_suppression (utils/general.py:611-703, best-class branch) + scale_coords/clip/round
  * (general.py:323-344, detector.py:142).  pred [n][5+nc] f32.  class_mask: bit c set = class c kept.

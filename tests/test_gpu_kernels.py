@@ -142,6 +142,9 @@ def test_gemm_persistent_kernel_exact(dt):
             wr = _u("pw", (N, K), 0.05, seed=N).to(DEV, dt)
             g26 = [ops.gemm(xr, wr, bd, L.HM_EPI_GELU) for _ in range(2)]
             s26 = ops.gemm(xr, wr, bd, L.HM_EPI_STORE)
+            for form in (1, 2):                                       # both epilogue forms (tile through LDS / lane swaps): the same bytes
+                with L.option(L.HM_OPT_PX_LDS_EPILOGUE, form):
+                    assert torch.equal(ops.gemm(xr, wr, bd, L.HM_EPI_GELU), g26[0]) and torch.equal(ops.gemm(xr, wr, bd, L.HM_EPI_STORE), s26), (M, N, K, form)
             L.check(lib.hm_gemm_set_variant(24))
             g24 = ops.gemm(xr, wr, bd, L.HM_EPI_GELU)
             s24 = ops.gemm(xr, wr, bd, L.HM_EPI_STORE)

@@ -32,7 +32,8 @@ def gemm_isa(tmp_path_factory):
 
 
 @pytest.mark.parametrize("kernel,min_loads", [
-    ("gemm_px_kernelI4TF16Li0E", 2), ("gemm_px_kernelI4TF16Li1E", 2), ("gemm_px_kernelI5TBf16Li0E", 2), ("gemm_px_kernelI5TBf16Li1E", 2),
+    ("gemm_px_kernelI4TF16Li0ELb1E", 2), ("gemm_px_kernelI4TF16Li1ELb1E", 2), ("gemm_px_kernelI5TBf16Li0ELb1E", 2), ("gemm_px_kernelI5TBf16Li1ELb1E", 2),
+    ("gemm_px_kernelI4TF16Li0ELb0E", 2), ("gemm_px_kernelI4TF16Li1ELb0E", 2),
     ("gemm_x3r_kernelI4TF16E", 32), ("gemm_x3r_kernelI5TBf16E", 32),
     ("gemm_fp8p_kernelILi2E", 16),
 ])

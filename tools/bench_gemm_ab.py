@@ -38,7 +38,8 @@ res = {}
 
 def setv(v):
     L.check(lib.hm_set_option(L.HM_OPT_RESID_IN_EPILOGUE, 1 if v == 200 else 0))
-    if v in (200, 201):             # 200 / 201: default tile with the fp32 residual fetched in the epilogue (round 2) / inside the K loop (round 3)
+    L.check(lib.hm_set_option(L.HM_OPT_PX_LDS_EPILOGUE, 1 if v == 202 else (2 if v == 201 else 0)))     # 202 / 201: persistent GEMM epilogue through LDS / by lane swaps
+    if v in (200, 201, 202):             # 200 / 201: default tile with the fp32 residual fetched in the epilogue (round 2) / inside the K loop (round 3)
         L.check(lib.hm_gemm_set_variant(-1)); L.check(lib.hm_gemm_set_group_m(8))
     elif v >= 100:
         L.check(lib.hm_gemm_set_variant(-1)); L.check(lib.hm_gemm_set_group_m(v - 100))

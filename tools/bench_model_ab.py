@@ -2,7 +2,7 @@
 """Interleaved A/B of WHOLE forwards (BASELINE configs[1]: B = 64 crops resident in HBM) under different library switches, in
 one process on one device: ROUNDS rounds, every round times STEPS steps of every configuration (wall clock around a
 synchronised region, the bench.py protocol).  Box-to-box noise is +-2 %; only numbers from one process compare.
-Configurations: CONFIGS="name:in_flight:opt=val,opt=val;..." with opt in {resid_epi, variant, px_grid, fold_ln}.
+Configurations: CONFIGS="name:in_flight:opt=val,opt=val;..." with opt in {resid_epi, variant, px_grid, px_lds_epi, fold_ln}.
 Default: serial and two-in-flight, residual in the epilogue (round 2) vs inside the K loop (round 3)."""
 import os
 import sys
@@ -49,6 +49,7 @@ img = synth.normalize_crops(synth.crops_u8(B, seed0=0)).cuda()
 def apply(o):
     L.check(lib.hm_set_option(L.HM_OPT_RESID_IN_EPILOGUE, int(o.get("resid_epi", 0))))
     L.check(lib.hm_set_option(L.HM_OPT_PX_GRID, int(o.get("px_grid", 0))))
+    L.check(lib.hm_set_option(L.HM_OPT_PX_LDS_EPILOGUE, int(o.get("px_lds_epi", 0))))
     L.check(lib.hm_gemm_set_variant(int(o.get("variant", -1))))
 
 

@@ -20,7 +20,7 @@ M = 64 * 192
 DT = torch.float16
 SHAPES = [("patch", 768, 1280, L.HM_EPI_RESID_F32), ("qkv", 1280, 3840, L.HM_EPI_STORE), ("proj", 1280, 1280, L.HM_EPI_RESID_F32),
           ("fc1", 1280, 5120, L.HM_EPI_GELU), ("fc2", 5120, 1280, L.HM_EPI_RESID_F32), ("kv", 1280, 6144, L.HM_EPI_STORE)]
-KERNELS = ("gemm_tn_kernel", "gemm_x3_kernel", "gemm_px_kernel", "layernorm_rows_kernel", "layernorm_kernel", "vit_attention_kernel")
+KERNELS = ("gemm_tn_kernel", "gemm_x3_kernel", "gemm_x3r_kernel", "gemm_px_kernel", "layernorm_rows_kernel", "layernorm_kernel", "vit_attention_kernel")
 if __name__ == "__main__":
     torch.manual_seed(0)
     bufs = []
