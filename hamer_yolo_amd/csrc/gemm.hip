@@ -1979,6 +1979,156 @@ int launch_gemm_epi(const KArgs& g, int epilogue, hipStream_t s) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Direct 3x3 convolution for the first layer of the detector (round 3): 3(8) -> 32 at 384 x 640 -- 6.5 % of the conv stack's time for
+// no flops to speak of.  As an implicit GEMM it is 30,720 workgroups of two K-steps each: all prologue and epilogue, at 3x its
+// HBM time.  (Written for Cin 8 / 32 / 64; the two layers behind the first were measured with it too and stay on the implicit
+// GEMM, see try_conv_direct.)  Here:
+//   * the WHOLE weight matrix ([Cout][9 Cin], <= 72 KB) sits in LDS for the life of a persistent workgroup (rows padded by 16 B:
+//     the 16 rows of an A fragment fall on 16 different 16-byte slots of the 256-byte bank row);
+//   * activations never touch LDS: the MFMA B operand of a K-step is, per lane, 16 contiguous bytes of ONE input pixel (8
+//     channels of tap (ky, kx)), so every lane loads its fragment straight from global memory -- 16 lanes x consecutive
+//     pixels = whole lines, the nine taps of a pixel hit L1 / L2 after the first;
+//   * a wave computes 64 consecutive output pixels of one row (4 tiles of 16) x all Cout channels, so a weight fragment read
+//     from LDS feeds 4 MFMAs, and its output is contiguous in NHWC; lane-swap epilogue (v_permlane16_swap) -> 16-byte stores.
+// K order, MFMA and epilogue arithmetic are the implicit GEMM's: results are bit-identical to it (test_conv_direct_stem_...).
+template <class T, int CIN, int COUT, int STRIDE, int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const KArgs g) {
+  using elem = typename T::elem;
+  using vec8 = typename T::vec8;
+  constexpr int NKS = (9 * CIN + 31) / 32;              // K-steps of 32: 3 (Cin 8: four taps per step), 9, 18
+  constexpr int WROW = NKS * 64 + 16;                   // bytes per weight row in LDS (padded)
+  constexpr int NT = COUT / 16, MP = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g4 = lane >> 4;
+  // weights -> LDS (K index = tap * CIN + ci as stored; columns >= 9 CIN of the padded rows are zero in the tensor itself)
+  for (int c = tid; c < COUT * NKS * 4; c += 256) {
+    const int row = c / (NKS * 4), ch = c - row * (NKS * 4);
+    *(vec8*)(smem + row * WROW + ch * 16) = *(const vec8*)((const elem*)g.W + (size_t)row * g.ldw + ch * 8);
+  }
+  f32x4_t bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const f32x4_t*)(g.bias + nt * 16 + 4 * g4);
+  __syncthreads();
+  vec8 zero8;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) zero8[q] = (elem)0.0f;
+  const int xblocks = (g.Wout + 63) / 64;
+  const int groups = (g.M / g.Wout) * xblocks;          // (image, output row) pairs x 64-pixel blocks
+  const elem* X = (const elem*)g.X;
+  for (int grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
+    const int rowi = grp / xblocks, x0 = (grp - rowi * xblocks) * 64;
+    const int n = rowi / g.Hout, oy = rowi - n * g.Hout;
+    const elem* img = X + (size_t)n * g.H * g.Wd * g.ldx;
+    f32x4_t acc[MP][NT];
+#pragma unroll
+    for (int p = 0; p < MP; ++p)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[p][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // this lane's B fragment of K-step ks for pixel tile p: 8 channels of one tap of pixel x0 + 16 p + li
+    auto load_b = [&](int ks, vec8 (&xf)[MP]) {
+      int tap, coff;
+      if (CIN == 8) { tap = 4 * ks + g4; coff = 0; }
+      else if (CIN == 32) { tap = ks; coff = 8 * g4; }
+      else { tap = ks >> 1; coff = (ks & 1) * 32 + 8 * g4; }
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int iy = oy * STRIDE - 1 + ky;
+      const bool rowok = tap < 9 && iy >= 0 && iy < g.H;
+#pragma unroll
+      for (int p = 0; p < MP; ++p) {
+        const int ox = x0 + 16 * p + li, ix = ox * STRIDE - 1 + kx;
+        const bool ok = rowok && ix >= 0 && ix < g.Wd && ox < g.Wout;
+        xf[p] = ok ? *(const vec8*)(img + ((size_t)iy * g.Wd + ix) * g.ldx + coff) : zero8;
+      }
+    };
+    vec8 xa[MP], xb[MP];
+    load_b(0, xa);
+    auto kstep = [&](int ks, const vec8 (&xf)[MP]) {
+      vec8 wf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const vec8*)(smem + (nt * 16 + li) * WROW + ks * 64 + g4 * 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int p = 0; p < MP; ++p) acc[p][nt] = T::mfma(wf[nt], xf[p], acc[p][nt]);
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < NKS; ks += 2) {                // next K-step's fragments in flight while this one's MFMAs run (a real
+                                                         // loop: unrolled, hipcc hoists every load and takes 256 registers)
+      if (ks + 1 < NKS) load_b(ks + 1, xb);
+      kstep(ks, xa);
+      if (ks + 1 < NKS) {
+        if (ks + 2 < NKS) load_b(ks + 2, xa);
+        kstep(ks + 1, xb);
+      }
+    }
+    // epilogue: + bias, activation, 16-bit; pairs of channel tiles -> 8 consecutive channels per lane by one lane swap per register
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    elem* yrow = (elem*)g.C + (size_t)rowi * g.Wout * g.ldc;
+#pragma unroll
+    for (int p = 0; p < MP; ++p) {
+      const int ox = x0 + 16 * p + li;
+#pragma unroll
+      for (int np = 0; np < NT / 2; ++np) {
+        unsigned pk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4_t a = acc[p][2 * np + h], bb = bv[2 * np + h];
+          typename T::vec4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = __fadd_rn(a[q], bb[q]);
+            if (ACT == 1) v = silu(v);
+            if (ACT == 2) v = fmaxf(v, 0.f);
+            o[q] = (elem)v;
+          }
+          const u32x2 w = __builtin_bit_cast(u32x2, o);
+          pk[h][0] = w[0]; pk[h][1] = w[1];
+        }
+        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        if (ox < g.Wout)
+          *(u32x4*)(yrow + (size_t)ox * g.ldc + (2 * np + (g4 & 1)) * 16 + (g4 >> 1) * 8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+  }
+}
+
+template <class T, int CIN, int COUT, int STRIDE, int ACT>
+int launch_conv_direct(const KArgs& g, hipStream_t s) {
+  constexpr int NKS = (9 * CIN + 31) / 32, LDS = COUT * (NKS * 64 + 16);
+  auto kern = conv3x3_direct_kernel<T, CIN, COUT, STRIDE, ACT>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_conv2d_nhwc: cannot raise the dynamic LDS limit")) return rc;
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int groups = (g.M / g.Wout) * ((g.Wout + 63) / 64);
+  const int per_cu = LDS > 64 * 1024 ? 2 : 4;                  // resident workgroups per CU (LDS-limited for the 72 KB matrix)
+  int grid = (groups + 3) / 4;
+  if (grid > cus * per_cu) grid = cus * per_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, g);
+  return hm_check_launch("hm_conv2d_nhwc (direct 3x3)");
+}
+
+// the stem shapes the direct kernel is built for; everything else (and HM_OPT_CONV_DIRECT = 1) takes the implicit GEMM
+template <class T>
+int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
+  taken = false;
+  if (hm_option(HM_OPT_CONV_DIRECT) == 1 || epilogue != HM_EPI_SILU || g.ksz != 3 || g.bias == nullptr || (g.ldc & 7) != 0 ||
+      (((uintptr_t)g.C) & 15) != 0 || g.ldw < ((9 << g.cin_log2) + 31) / 32 * 32)
+    return HM_OK;
+  const int cin = 1 << g.cin_log2;
+  taken = true;
+  // Measured per layer, 16 frames of 1080p (tools/prof_yolo.py): 3(8) -> 32: 192 -> 93 us (one frame 18 -> 11.5); 32 -> 64 stride 2:
+  // 128 -> 134 and 64 -> 64: 143 -> 161 -- with 9 / 18 K-steps of four dependent global loads each and two waves per SIMD the
+  // direct form is bound by load latency there (it would need a ring of fragments many K-steps deep): only the first layer takes it.
+  if (cin == 8 && g.N == 32 && g.stride == 1) return launch_conv_direct<T, 8, 32, 1, 1>(g, s);
+  taken = false;
+  return HM_OK;
+}
+
 // Convolution tiles.  Round 2 had the 128-row, four-wave, two-workgroups-per-CU tile only (128 x 128 / 64 / 32); round 3 adds the
 // eight-wave 256-row tiles of the ViT GEMM (256 x 256 / 128 / 64: half the operand bytes per flop) for the layers whose output
 // has enough of them to fill the chip, and split-K (below) for the layers that have too few tiles of any shape.
@@ -2075,6 +2225,11 @@ int conv_split_rule(const KArgs& g) {
 template <class T>
 int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStream_t s) {
   KArgs g = g0;
+  {
+    bool taken = false;
+    const int rc = try_conv_direct<T>(g, epilogue, s, taken);
+    if (taken || rc != HM_OK) return rc;
+  }
   const bool act_ok = epilogue == HM_EPI_STORE || epilogue == HM_EPI_SILU || epilogue == HM_EPI_RELU;
   int ks = (ws && g.bias && act_ok && (((uintptr_t)ws) & 15) == 0) ? conv_split_rule(g) : 1;
   if (ks > 1 && (size_t)ks * g.M * g.N * 4 > ws_bytes)

@@ -97,6 +97,27 @@ def test_conv_every_tile_exact_and_equal(tile):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Co,s,H,W", [(3, 32, 1, 20, 72), (3, 32, 1, 9, 150), (3, 32, 1, 33, 64), (3, 32, 1, 5, 640)])
+def test_conv_direct_stem_kernel_equals_the_implicit_gemm(Ci, Co, s, H, W, dt):
+    """Round 3: the first convolution of the detector (3x3, 3(8) -> 32) runs on conv3x3_direct_kernel -- the whole
+    weight matrix resident in LDS, activations loaded straight into MFMA fragments, 64 output pixels of a row per wave, lane-swap
+    epilogue.  Same K order, MFMA and epilogue arithmetic as the implicit GEMM: the bytes must be equal to it
+    (HM_OPT_CONV_DIRECT = 1 selects the implicit GEMM), for widths that are and are not multiples of the 64-pixel wave tile, odd
+    heights under stride 2, inputs and outputs that are channel slices of wider buffers; and both match torch."""
+    x = synth.uniform("dx", (2, Ci, H, W), 1.0, seed=Ci + W).to(dt).float()
+    w = synth.uniform("dw", (Co, Ci, 3, 3), (3.0 / (Ci * 9)) ** 0.5, seed=Co).to(dt).float()
+    b = synth.uniform("db", (Co,), 0.3, seed=3)
+    ld_extra = 8 if Ci >= 8 else 0
+    direct = _conv_gpu(x, w, b, 3, s, act=True, dt=dt, ld_extra=ld_extra, y_extra=8)
+    with L.option(L.HM_OPT_CONV_DIRECT, 1):
+        gemm = _conv_gpu(x, w, b, 3, s, act=True, dt=dt, ld_extra=ld_extra, y_extra=8)
+    assert torch.equal(direct, gemm)
+    ref = F.silu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=1)).float()
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    np.testing.assert_allclose(direct.numpy(), ref.numpy(), atol=2e-3, rtol=2 * ulp)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_conv_split_k_exact_and_close(dt):
     """Split-K convolution (hm_conv_args.splitk_ws: few output tiles, long K -- the 12x20 / 24x40 maps of the YOLOv7 neck):
     fp32 partial slabs per K range, added in order by the reduce kernel, then bias + SiLU.  Exact on integer data for 2, 4 and
