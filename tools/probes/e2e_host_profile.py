@@ -11,7 +11,7 @@ from runlog import banner
 banner()
 
 class YCfg:
-    weights = "synthetic:2:-2.2:0"; imgsz = 640; augment = True; conf_thres = 0.25; iou_thres = 0.35
+    weights = os.environ.get("YOLO_WEIGHTS", "synthetic:2:-2.53:0"); imgsz = 640; augment = True; conf_thres = 0.25; iou_thres = 0.35
     classes = [0, 1, 2]; agnostic_nms = True; device = "cuda"; save_path = "./output"
 class HCfg:
     ckpt_path = "synthetic:0"; model_cfg = None; use_onnx = False; onnx_path = None
