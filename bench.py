@@ -164,7 +164,7 @@ def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass
 E2E_WEIGHTS_4_HANDS = "synthetic:2:-2.53:0"     # objectness bias calibrated on the 8 seeded frames to ~4 boxes per frame (tools/probes/yolo_hands_per_frame.py)
 
 
-def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value):
+def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value, ctxs):
     """The other single-GPU BASELINE configurations, timed briefly in the same process so that the driver's one command observes
     them too.  Not the contract line: `value` above stays configs[1].  ~40 s in all."""
     import types
@@ -172,7 +172,7 @@ def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value):
     t_all = time.perf_counter()
     # configs[3] at N = 1: the shard job (1024 crops, forwards of 64 on two contexts, pack + gather) -- shard.ShardJob
     mine = synth.normalize_crops(synth.crops_u8(1024, seed0=0)).to(dev)
-    job = shard.ShardJob(eng, mine, 1024, batch=64, in_flight=2)
+    job = shard.ShardJob(eng, mine, 1024, batch=64, in_flight=2, contexts=ctxs)    # the contract line's own streams and workspaces
     job.step(); job.step(); torch.cuda.synchronize()          # (two warm-up jobs: the profiling pass before this left the chip idle)
     NJ = 3
     t0 = time.perf_counter()
@@ -212,7 +212,7 @@ def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value):
     torch.cuda.empty_cache()
     # configs[2]: 1080p frames through the product driver, detector calibrated to ~4 hands per frame
     a2 = types.SimpleNamespace(frames=16, steps=2, warmup=1, workload="e2e", dtype="fp16")
-    r = run_e2e(a2, dev, torch.float16, yolo_weights=E2E_WEIGHTS_4_HANDS, chunks_per_pass=8)
+    r = run_e2e(a2, dev, torch.float16, yolo_weights=E2E_WEIGHTS_4_HANDS, chunks_per_pass=4)
     out["configs[2] e2e 1080p, ~4 hands/frame"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "frames_per_pass", "hands_per_frame", "frames_per_s",
                                                                       "npy_files_per_pass", "dtype", "gflop_per_frame")}
     out["configs[2] e2e 1080p, ~4 hands/frame"]["detector_weights"] = E2E_WEIGHTS_4_HANDS
@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=-1, help="force one GEMM tile variant (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the short runs of the other single-GPU BASELINE configurations ('side_configs')")
+    ap.add_argument("--chunks", type=int, default=4, help="e2e: chunks of --frames frames per pass (a step = one pass over frames x chunks files)")
     ap.add_argument("--hands4", action="store_true", help="e2e: detector weights calibrated to ~4 hands per frame (configs[2]'s wording) instead of ~8.6")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -307,7 +308,8 @@ def main():
     B = args.batch
 
     if args.workload in ("e2e", "e2e-depth"):
-        print(json.dumps(run_e2e(args, dev, dtype, yolo_weights=E2E_WEIGHTS_4_HANDS if args.hands4 else "synthetic:2:-2.2:0")), flush=True)
+        print(json.dumps(run_e2e(args, dev, dtype, yolo_weights=E2E_WEIGHTS_4_HANDS if args.hands4 else "synthetic:2:-2.2:0",
+                                 chunks_per_pass=args.chunks)), flush=True)
         return
 
     # weights: rank 0 draws the synthetic checkpoint (fp32 master weights), RCCL broadcasts it as two flat buffers
@@ -450,9 +452,7 @@ def main():
     default_line = (world == 1 and args.workload == "crops" and args.dtype == "fp16" and B == 64 and not args.token_merge
                     and not args.fold_ln and args.gemm_variant < 0)
     if rank == 0 and default_line and not args.no_side:
-        del ctxs
-        torch.cuda.empty_cache()
-        res["side_configs"] = side_configs(args, dev, cfg, sd, mano_cpu, eng, res["value"])
+        res["side_configs"] = side_configs(args, dev, cfg, sd, mano_cpu, eng, res["value"], ctxs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, sd, mano_cpu)
     if world > 1:

@@ -110,12 +110,15 @@ class ShardJob:
     (--workload shard1024) and tests/test_gpu_shard.py run the same step() -- the reference's counterpart is the serial
     one-hand loop at hamer/infer.py:1268-1274."""
 
-    def __init__(self, eng, crops: Optional[torch.Tensor], n_total: int, batch: int = 64, in_flight: int = 2):
+    def __init__(self, eng, crops: Optional[torch.Tensor], n_total: int, batch: int = 64, in_flight: int = 2, contexts=None):
         import torch as _t
         self.eng, self.n_total, self.batch = eng, n_total, batch
         self.crops = crops                                        # (n_mine, 3, 256, 256) f32 on the device, or None when this rank holds nothing
         n = 0 if crops is None else crops.shape[0]
-        self.ctxs = eng.contexts(batch, in_flight)
+        # (contexts: reuse a caller's (stream, workspace, outputs) triples of the same batch size.  HIP maps streams onto a few
+        # hardware queues; a process that has already created a pair gets another mapping for the next pair, and two pairs do
+        # not overlap alike -- measured: the same job 6 % slower on a second pair of streams)
+        self.ctxs = contexts if contexts is not None else eng.contexts(batch, in_flight)
         self.pieces = [(a, min(a + batch, n)) for a in range(0, n, batch)]
         self.packed = _t.zeros(n, PARAMS_PER_HAND, device=eng.device)
         self._tail_out = None
