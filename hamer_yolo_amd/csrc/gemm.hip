@@ -472,6 +472,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
 #pragma unroll
     for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
     if (SCHED >= 1) __builtin_amdgcn_s_setprio(1);
+#ifdef HM_ABLATIONS
+    if constexpr (SCHED == 98) {
+      // timing ablation (WRONG results): the same fragment reads feeding HALF as many, twice as long MFMAs (32x32x16 instead of
+      // 16x16x32): is the K loop bound by vector-instruction ISSUE (an MFMA holds the issue port 8 cycles whatever its shape)?
+      typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+      static_assert(NI == 8 && MI == 4, "written for the 64 x 128 wave tile");
+      f32x16_t* a32 = (f32x16_t*)&acc[0][0];                // 8 accumulators of 16 registers over the same 128 registers
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            if constexpr (std::is_same<T, TF16>::value) a32[nb * 2 + mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nb * 2 + kk], xf[mb * 2 + kk], a32[nb * 2 + mb], 0, 0, 0);
+            else a32[nb * 2 + mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb * 2 + kk], xf[mb * 2 + kk], a32[nb * 2 + mb], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      return;
+    }
+#endif
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -530,7 +550,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   }
 
   __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring: reuse it for the epilogue
-  if (SCHED == 96) {                                    // ablation: no epilogue (keep the accumulators alive)
+  if (SCHED == 96 || SCHED == 98) {                     // ablation: no epilogue (keep the accumulators alive)
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
@@ -1921,6 +1941,7 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
     case 15: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 93>(g, s, "hm_gemm"); // ds_read + MFMA + barriers, no loads
     case 20: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 96>(g, s, "hm_gemm"); // no epilogue
     case 18: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 97>(g, s, "hm_gemm"); // every tile loads operand panel 0 (pure L2 hits)
+    case 32: return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 98>(g, s, "hm_gemm"); // K loop on 32x32x16 MFMAs (half the MFMA issues), no epilogue
 #endif
     default: return hm_set_error(HM_ERR_ARG, "hm_gemm: unknown tile variant");
   }
@@ -1940,7 +1961,7 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 28 && v <= 31)) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 28 && v <= 32)) return true;
 #endif
   return false;
 }
