@@ -40,9 +40,6 @@ def parse_tome_r(num_layers: int, r):
     return [int(lo + step * i) for i in range(num_layers)]
 
 
-_CONTEXT_STREAMS: Dict = {}     # (device, n) -> the n HIP streams every HamerEngine.contexts(B, n) hands out
-
-
 class ForwardContext:
     """One batch in flight: its own HIP stream, workspace and output tensors (HamerEngine.contexts)."""
 
@@ -228,14 +225,11 @@ class HamerEngine:
         on alternating contexts overlap -- the HBM-bound phases of one batch (LayerNorm, attention, GEMM epilogues, decoder)
         run under the MFMA phases of the other (measured: +6 % hands/s at B=64 with 2, x1.85 at B=16 with 3)."""
         nbytes = self.lib.hm_hamer_workspace_bytes(C.byref(self.w), B)
-        # The n streams are created once per device and shared by every engine and every call: HIP maps streams onto a few
-        # hardware queues in creation order, and a second pair of streams in the same process overlaps differently from the
-        # first (measured: the same 1024-crop job 6 % slower on a second pair).
-        key = (str(self.device), n)
-        if key not in _CONTEXT_STREAMS:
-            _CONTEXT_STREAMS[key] = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        # the n streams come from the package's one shared set per device (streams.py: a second set of streams in the same
+        # process may share a hardware queue and then does not overlap at all)
+        from .streams import get_streams
         return [ForwardContext(st, torch.empty(nbytes, dtype=torch.uint8, device=self.device), self.alloc_outputs(B, want_tokens))
-                for st in _CONTEXT_STREAMS[key]]
+                for st in get_streams(self.device, n)]
 
     def forward_on(self, ctx: ForwardContext, img: torch.Tensor, want_tokens: bool = False) -> Dict[str, torch.Tensor]:
         """forward() enqueued on ctx.stream (after everything already queued on the caller's current stream, so `img` is
