@@ -170,53 +170,62 @@ def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value, ctxs):
     import types
     out = {}
     t_all = time.perf_counter()
-    # configs[3] at N = 1: the shard job (1024 crops, forwards of 64 on two contexts, pack + gather) -- shard.ShardJob
-    mine = synth.normalize_crops(synth.crops_u8(1024, seed0=0)).to(dev)
-    job = shard.ShardJob(eng, mine, 1024, batch=64, in_flight=2, contexts=ctxs)    # the contract line's own streams and workspaces
-    job.step(); job.step(); torch.cuda.synchronize()          # (two warm-up jobs: the profiling pass before this left the chip idle)
-    NJ = 3
-    t0 = time.perf_counter()
-    for _ in range(NJ):
-        last = job.step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    assert last.shape == (1024, shard.PARAMS_PER_HAND) and bool(torch.isfinite(last).all())
-    out["configs[3] shard1024, N=1"] = {"value": round(NJ * 1024 / el, 1), "unit": "hands/s", "ms_per_job": round(el / NJ * 1e3, 2), "jobs": NJ,
-                                        "vs_contract_line": round(NJ * 1024 / el / contract_value, 4), "dtype": "fp16"}
-    del job, mine
-    torch.cuda.empty_cache()
-    # configs[4]: fp8 ViT-H, B = 256, two batches in flight
-    e8 = HamerEngine(sd, mano_cpu, cfg, device=dev, fp8=True)
-    c8 = e8.contexts(256, 2)
-    img8 = synth.normalize_crops(synth.crops_u8(256, seed0=0)).to(dev)
+    only = os.environ.get("HAMER_BENCH_SIDE", "shard,fp8,e2e").split(",")     # (debugging: a subset of the side configurations)
 
-    def step8(i):
-        c = c8[i % 2]
-        with torch.cuda.stream(c.stream):
-            e8.forward(img8, c.out, workspace=c.workspace)
-    for i in range(4):
-        step8(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(8):
-        step8(i)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    assert all(bool(torch.isfinite(c.out["pred_vertices"]).all()) for c in c8)
-    fl = flops_per_hand(cfg)["total_mfma"]
-    out["configs[4] fp8 ViT-H, B=256"] = {"value": round(8 * 256 / el, 1), "unit": "hands/s", "ms_per_step": round(el / 8 * 1e3, 2), "steps": 8,
-                                          "dtype": "fp8 (e4m3 weights, MXFP8 activations) / bf16 / fp32",
-                                          "model_frac_of_fp8_peak": round(8 * 256 / el * fl / 1e12 / PEAK_FP8_TFLOPS, 4),
-                                          "parity_note": "vertices 3.5e-3 from the fp32 reference (DESIGN.md): not the 1e-3 configuration"}
-    del e8, c8, img8
-    torch.cuda.empty_cache()
-    # configs[2]: 1080p frames through the product driver, detector calibrated to ~4 hands per frame
-    a2 = types.SimpleNamespace(frames=16, steps=2, warmup=1, workload="e2e", dtype="fp16")
-    r = run_e2e(a2, dev, torch.float16, yolo_weights=E2E_WEIGHTS_4_HANDS, chunks_per_pass=4)
-    out["configs[2] e2e 1080p, ~4 hands/frame"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "frames_per_pass", "hands_per_frame", "frames_per_s",
-                                                                      "npy_files_per_pass", "dtype", "gflop_per_frame")}
-    out["configs[2] e2e 1080p, ~4 hands/frame"]["detector_weights"] = E2E_WEIGHTS_4_HANDS
-    torch.cuda.empty_cache()
+    def side_shard():
+        # configs[3] at N = 1: the shard job (1024 crops, forwards of 64 on two contexts, pack + gather) -- shard.ShardJob
+        mine = synth.normalize_crops(synth.crops_u8(1024, seed0=0)).to(dev)
+        job = shard.ShardJob(eng, mine, 1024, batch=64, in_flight=2, contexts=ctxs)    # the contract line's own streams and workspaces
+        job.step(); job.step(); torch.cuda.synchronize()      # (two warm-up jobs: the profiling pass before this left the chip idle)
+        NJ = 3
+        t0 = time.perf_counter()
+        for _ in range(NJ):
+            last = job.step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert last.shape == (1024, shard.PARAMS_PER_HAND) and bool(torch.isfinite(last).all())
+        return {"value": round(NJ * 1024 / el, 1), "unit": "hands/s", "ms_per_job": round(el / NJ * 1e3, 2), "jobs": NJ,
+                "vs_contract_line": round(NJ * 1024 / el / contract_value, 4), "dtype": "fp16"}
+
+    def side_fp8():
+        # configs[4]: fp8 ViT-H, B = 256, two batches in flight
+        e8 = HamerEngine(sd, mano_cpu, cfg, device=dev, fp8=True)
+        c8 = e8.contexts(256, 2)
+        img8 = synth.normalize_crops(synth.crops_u8(256, seed0=0)).to(dev)
+
+        def step8(i):
+            c = c8[i % 2]
+            with torch.cuda.stream(c.stream):
+                e8.forward(img8, c.out, workspace=c.workspace)
+        for i in range(4):
+            step8(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(8):
+            step8(i)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert all(bool(torch.isfinite(c.out["pred_vertices"]).all()) for c in c8)
+        fl = flops_per_hand(cfg)["total_mfma"]
+        return {"value": round(8 * 256 / el, 1), "unit": "hands/s", "ms_per_step": round(el / 8 * 1e3, 2), "steps": 8,
+                "dtype": "fp8 (e4m3 weights, MXFP8 activations) / bf16 / fp32",
+                "model_frac_of_fp8_peak": round(8 * 256 / el * fl / 1e12 / PEAK_FP8_TFLOPS, 4),
+                "parity_note": "vertices 3.5e-3 from the fp32 reference (DESIGN.md): not the 1e-3 configuration"}
+
+    def side_e2e():
+        # configs[2]: 1080p frames through the product driver, detector calibrated to ~4 hands per frame
+        a2 = types.SimpleNamespace(frames=16, steps=3, warmup=1, workload="e2e", dtype="fp16")
+        r = run_e2e(a2, dev, torch.float16, yolo_weights=E2E_WEIGHTS_4_HANDS, chunks_per_pass=4)
+        o = {k: r[k] for k in ("value", "unit", "ms_per_step", "frames_per_pass", "hands_per_frame", "frames_per_s", "npy_files_per_pass",
+                               "dtype", "gflop_per_frame")}
+        o["detector_weights"] = E2E_WEIGHTS_4_HANDS
+        return o
+
+    for key, name, fn in (("shard", "configs[3] shard1024, N=1", side_shard), ("fp8", "configs[4] fp8 ViT-H, B=256", side_fp8),
+                          ("e2e", "configs[2] e2e 1080p, ~4 hands/frame", side_e2e)):
+        if key in only:
+            out[name] = fn()
+            torch.cuda.empty_cache()
     out["seconds"] = round(time.perf_counter() - t_all, 1)
     return out
 

@@ -9,12 +9,13 @@ from typing import Dict, List
 
 import torch
 
-_STREAMS: Dict[str, List["torch.cuda.Stream"]] = {}
+_STREAMS: Dict[int, List["torch.cuda.Stream"]] = {}
 
 
 def get_streams(device, n: int) -> List["torch.cuda.Stream"]:
     """The first `n` of this device's shared streams (created on first use, in order)."""
-    key = str(torch.device(device))
+    d = torch.device(device)
+    key = d.index if d.index is not None else torch.cuda.current_device()      # "cuda" and "cuda:0" are the same device
     pool = _STREAMS.setdefault(key, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
