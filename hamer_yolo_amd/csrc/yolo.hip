@@ -60,10 +60,12 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const E* __restrict__ x
 template <class E>
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ frame, hm_letterbox_plan pl,
                                                         const int32_t* __restrict__ tab, E* __restrict__ x8,
-                                                        uint8_t* __restrict__ u8) {
+                                                        uint8_t* __restrict__ u8, size_t frame_stride) {
   typedef __attribute__((ext_vector_type(8))) E vec8;
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= pl.out_h * pl.out_w) return;
+  frame += (size_t)blockIdx.y * frame_stride;           // frame blockIdx.y of a batched pass; its output follows the previous one's
+  x8 += (size_t)blockIdx.y * pl.out_h * pl.out_w * 8;
   const int oy = pix / pl.out_w, ox = pix - oy * pl.out_w;
   const int dy = oy - pl.top, dx = ox - pl.left;
   int v[3] = {114, 114, 114};                               // BGR, letterbox colour (datasets.py:999)
@@ -378,10 +380,27 @@ extern "C" int hm_letterbox(const uint8_t* frame, const hm_letterbox_plan* plan,
   HmProfScope prof(HM_K_OTHER, 3, plan->out_h, plan->out_w, 0, s);
   const int rc = with_dtype(dtype, [&](auto* tag) {
     using E = std::remove_pointer_t<decltype(tag)>;
-    hipLaunchKernelGGL(letterbox_kernel<E>, dim3((total + 255) / 256), dim3(256), 0, s, frame, *plan, tab_dev, (E*)x8, u8_chw);
+    hipLaunchKernelGGL(letterbox_kernel<E>, dim3((total + 255) / 256), dim3(256), 0, s, frame, *plan, tab_dev, (E*)x8, u8_chw, (size_t)0);
     return HM_OK;
   });
   return rc != HM_OK ? rc : hm_check_launch("hm_letterbox");
+}
+
+extern "C" int hm_letterbox_batch(const uint8_t* frames, size_t frame_stride_bytes, int nb, const hm_letterbox_plan* plan,
+                                  const int32_t* tab_dev, void* x8, int dtype, void* stream_) {
+  if (!frames || !plan || !tab_dev || !x8 || nb <= 0 || nb > 65535) return hm_set_error(HM_ERR_ARG, "hm_letterbox_batch: bad arguments");
+  if ((uintptr_t)x8 & 15) return hm_set_error(HM_ERR_ARG, "hm_letterbox_batch: x8 must be 16-byte aligned");
+  if (frame_stride_bytes < (size_t)plan->src_h * plan->src_w * 3) return hm_set_error(HM_ERR_ARG, "hm_letterbox_batch: frame stride smaller than a frame");
+  const int total = plan->out_h * plan->out_w;
+  hipStream_t s = (hipStream_t)stream_;
+  HmProfScope prof(HM_K_OTHER, 3, plan->out_h, plan->out_w, nb, s);
+  const int rc = with_dtype(dtype, [&](auto* tag) {
+    using E = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(letterbox_kernel<E>, dim3((total + 255) / 256, nb), dim3(256), 0, s, frames, *plan, tab_dev, (E*)x8, (uint8_t*)nullptr,
+                       frame_stride_bytes);
+    return HM_OK;
+  });
+  return rc != HM_OK ? rc : hm_check_launch("hm_letterbox_batch");
 }
 
 extern "C" int hm_yolo_decode(const float* raw, int ldraw, float* pred, int row0, int ny, int nx, int nc, float stride,

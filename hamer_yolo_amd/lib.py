@@ -25,7 +25,7 @@ EXPORTS = [
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
-    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes", "hm_yolo_decode_batch",
+    "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes", "hm_yolo_decode_batch", "hm_letterbox_batch",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -154,6 +154,7 @@ def load() -> C.CDLL:
     lib.hm_letterbox_plan_make.argtypes = [i, i, i, i, C.POINTER(LetterboxPlan)]
     lib.hm_letterbox_tables.argtypes = [C.POINTER(LetterboxPlan), C.POINTER(C.c_int32)]
     lib.hm_letterbox.argtypes = [vp, C.POINTER(LetterboxPlan), vp, vp, i, vp, vp]
+    lib.hm_letterbox_batch.argtypes = [vp, C.c_size_t, i, C.POINTER(LetterboxPlan), vp, vp, i, vp]
     lib.hm_yolo_decode.argtypes = [vp, i, vp, i, i, i, i, f, C.POINTER(C.c_float), vp]
     lib.hm_yolo_decode_batch.argtypes = [vp, i, vp, i, i, i, i, f, C.POINTER(C.c_float), i, C.c_size_t, vp]
     lib.hm_nms_workspace_bytes.argtypes = [i]

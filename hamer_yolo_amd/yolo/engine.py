@@ -274,8 +274,18 @@ class YoloEngine:
                 raise L.HipLibraryError("YoloEngine.forward takes uint8 device frames of one size")
         H, W, _ = frames[0].shape
         p = self._plan(H, W, len(frames))
-        for i, f in enumerate(frames):
-            self.letterbox(f.contiguous(), want_u8 and len(frames) == 1, p, i)
+        # frames that are equally spaced slices of one device tensor (the folder drivers upload a chunk as one tensor): ONE
+        # letterbox launch for the pass; otherwise one per frame
+        nb = len(frames)
+        stride = frames[1].data_ptr() - frames[0].data_ptr() if nb > 1 else 0
+        batched = nb > 1 and stride >= H * W * 3 and all(f.is_contiguous() for f in frames) and \
+            all(frames[i].data_ptr() - frames[0].data_ptr() == i * stride for i in range(nb))
+        if batched:
+            L.check(self.lib.hm_letterbox_batch(frames[0].data_ptr(), stride, nb, C.byref(p["lp"]), p["tab"].data_ptr(), p["img_ptr"],
+                                                self.dt, L.current_stream()), "hm_letterbox_batch")
+        else:
+            for i, f in enumerate(frames):
+                self.letterbox(f.contiguous(), want_u8 and len(frames) == 1, p, i)
         st = L.current_stream()
         L.check(self.lib.hm_yolo_run(p["ops"], p["n_ops"], st), "hm_yolo_run")
         row0 = 0

@@ -365,6 +365,10 @@ int hm_letterbox_tables(const hm_letterbox_plan* plan, int32_t* tab_host);
  * u8_chw [3][out_h][out_w] RGB (the reference's uint8 network input, for parity checks). */
 int hm_letterbox(const uint8_t* frame, const hm_letterbox_plan* plan, const int32_t* tab_dev, void* x8, int dtype,
                  uint8_t* u8_chw, void* stream);
+/* `nb` equally sized frames, frame i at frames + i * frame_stride_bytes, into x8 [nb][out_h][out_w][8] in one launch (round 3:
+ * the folder drivers upload a chunk's frames as one tensor). */
+int hm_letterbox_batch(const uint8_t* frames, size_t frame_stride_bytes, int nb, const hm_letterbox_plan* plan,
+                       const int32_t* tab_dev, void* x8, int dtype, void* stream);
 
 /* Detect decode (IDetect.fuseforward, yolo.py:148-184): raw [ny*nx][3*(5+nc)] f32 of one level ->
  * rows [row0 + a*ny*nx + y*nx + x][5+nc] of pred: sigmoid, xy = (2s-0.5+grid)*stride, wh = (2s)^2*anchor. */

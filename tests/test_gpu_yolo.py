@@ -410,3 +410,10 @@ def test_batched_frames_equal_single_frame_passes(engine):
         assert torch.equal(pb["pred"][i * n:(i + 1) * n], singles[i])
     detsb = engine.nms(pb, 0.25, 0.35, [0, 1, 2], True)
     assert len(detsb) == 3 and all(torch.equal(a.cpu(), b) for a, b in zip(detsb, dets1))
+    # frames that are slices of ONE device tensor (how the folder drivers upload a chunk) take the one-launch letterbox
+    # (hm_letterbox_batch): same predictions again
+    stacked = torch.stack(frames)
+    ps = engine.forward([stacked[i] for i in range(3)])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(ps["pred"][i * n:(i + 1) * n], singles[i])
