@@ -2252,7 +2252,7 @@ int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStr
     if (taken || rc != HM_OK) return rc;
   }
   const bool act_ok = epilogue == HM_EPI_STORE || epilogue == HM_EPI_SILU || epilogue == HM_EPI_RELU;
-  int ks = (ws && g.bias && act_ok && (((uintptr_t)ws) & 15) == 0) ? conv_split_rule(g) : 1;
+  int ks = (ws && g.bias && act_ok && ((((uintptr_t)ws) | ((uintptr_t)g.C)) & 15) == 0) ? conv_split_rule(g) : 1;   // (the reduce kernel stores 16 bytes per lane)
   if (ks > 1 && (size_t)ks * g.M * g.N * 4 > ws_bytes)
     return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: splitk_ws too small (hm_conv_splitk_bytes gives the size; the split must not depend on what fits)");
   const int t = pick_conv_tile(g, ks);

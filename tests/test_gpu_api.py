@@ -174,3 +174,21 @@ def test_process_batch_npz_and_mask_driver(hi, tmp_path):
     np.testing.assert_allclose(px, (uv[:, :2] / uv[:, 2:3]).astype(np.int32), atol=1)
     assert sorted(order.tolist()) == list(range(1538))
     assert load_obj(str(tmp_path / "nope.obj")) == (None, None)
+
+
+def test_one_shared_set_of_streams_per_device():
+    """HIP deals streams onto a few hardware queues in creation order and two streams on one queue do not overlap (3 of 15 pairs,
+    tools/probes/stream_pairs.py), so the package keeps ONE set per device: the engine's contexts and the folder drivers get the
+    same stream objects, and 'cuda' / 'cuda:0' name the same set."""
+    import torch
+    from hamer_yolo_amd import infer, streams, synth
+    from hamer_yolo_amd.engine import HamerEngine
+    a = streams.get_streams("cuda", 2)
+    b = streams.get_streams(torch.device("cuda", torch.cuda.current_device()), 2)
+    assert a[0] is b[0] and a[1] is b[1] and a[0] is not a[1]
+    assert streams.get_streams("cuda:0", 3)[:2] == a
+    cfg = synth.tiny_config()
+    eng = HamerEngine(synth.hamer_state_dict(cfg, seed=0), synth.mano_params(seed=0), cfg, device="cuda:0")
+    ctxs = eng.contexts(2, 2)
+    assert ctxs[0].stream is a[0] and ctxs[1].stream is a[1]
+    assert infer._driver_streams(torch.device("cuda"), 2) == a

@@ -31,6 +31,20 @@ def test_library_exports_every_declared_symbol():
     assert lib.hm_version() == L.HM_VERSION == int(re.search(r"#define HM_VERSION (\d+)", hdr).group(1))
 
 
+def test_round3_entry_points_reject_bad_arguments_without_gpu():
+    lib = L.load()
+    assert lib.hm_letterbox_batch(None, 0, 1, None, None, None, 0, None) != 0
+    assert lib.hm_yolo_decode_batch(None, 24, None, 0, 12, 20, 3, 32.0, None, 1, 15120, None) != 0
+    assert lib.hm_tome_merge_metric(None, 80, 0, None, None, None, None, None, 1, 192, 8, 1280, None) != 0
+    assert lib.hm_conv_splitk_bytes(None) == 0
+    a = L.ConvArgs(1, 1, 1, 1, 1, 16, 12, 20, 256, 256, 3, 1, 256, 256, 2304, 1, 0, L.HM_DTYPE_F16)     # a 12x20 map, K = 2304: 4 ranges
+    assert lib.hm_conv_splitk_bytes(C.byref(a)) == 4 * 16 * 12 * 20 * 256 * 4
+    b = L.ConvArgs(1, 1, 1, 1, 1, 16, 96, 160, 64, 64, 3, 1, 64, 64, 576, 1, 0, L.HM_DTYPE_F16)         # a large map: never split
+    assert lib.hm_conv_splitk_bytes(C.byref(b)) == 0
+    one = L.ConvArgs(1, 1, 1, 1, 1, 1, 12, 20, 256, 256, 3, 1, 256, 256, 2304, 1, 0, L.HM_DTYPE_F16)    # the rule looks at ONE image: the same ranges for 1 frame
+    assert lib.hm_conv_splitk_bytes(C.byref(one)) == 4 * 1 * 12 * 20 * 256 * 4
+
+
 def test_options_are_explicit_setters_not_environment_reads(monkeypatch):
     """launch paths must not call getenv (a stray variable or a test's setenv would change which kernel runs).
     The switches live behind hm_set_option / hm_get_option; only the two start-up tuning defaults are read from the
