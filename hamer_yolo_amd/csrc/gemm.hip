@@ -2133,7 +2133,216 @@ int launch_conv_direct(const KArgs& g, hipStream_t s) {
   return hm_check_launch("hm_conv2d_nhwc (direct 3x3)");
 }
 
-// the stem shapes the direct kernel is built for; everything else (and HM_OPT_CONV_DIRECT = 1) takes the implicit GEMM
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3, stride 1, 64 -> 64 channels on the large maps (round 3): the second stem layer at 384 x 640 and the 3x3s of the first two
+// E-ELAN stages -- eight layers, 13 % of the conv stack's time at a quarter of the rate of the deep layers.  As an implicit
+// GEMM (K = 576: nine K-steps) every output tile re-fetches each input pixel nine times through LDS-DMA and streams 72 KB of
+// weights per 128 pixels, with a prologue and an epilogue per nine steps.  Here:
+//   * the weights never touch LDS: a wave owns 32 output channels and keeps their whole [32][576] slice as MFMA A fragments in
+//     registers (36 fragments = 144 VGPRs) for the life of a persistent workgroup;
+//   * the input is staged ONCE per output tile: the 10 x 18 pixel halo of an 8 x 16 pixel tile (180 rows of 128 bytes, the
+//     GEMM's 16-byte-chunk XOR swizzle) comes in by LDS-DMA, double-buffered -- the next tile's halo is fetched while this
+//     tile's nine taps run; the B fragment of (tap, pixel row) is the same LDS rows shifted by (ky, kx).  The swizzle key of a
+//     fragment is (lane + m) & 7 with m a compile-time constant of (tap, pixel row), and the second K sub-step's key is m + 4:
+//     eight lane addresses, computed once, and an immediate offset serve all 72 reads of a tile;
+//   * the copy addresses are tile-invariant too (per-lane byte offsets from the tile's first halo pixel, one register per copy;
+//     a tile on the map's border takes a slower per-lane path that substitutes the zero line);
+//   * one barrier per TILE (none per K-step): within a tile nothing is in flight that the MFMAs wait for;
+//   * the wait before that barrier is counted: the four stores of the previous tile's epilogue are the newest operations and may
+//     stay in flight (whole tiles; a tile that overhangs the map masks lanes, so it takes vmcnt(0)).
+// Four waves = 2 pixel groups (4 map rows each) x 2 channel halves; wave tile 64 pixels x 32 channels.  K order (tap-major, 32
+// deep MFMA steps) and the epilogue arithmetic are the implicit GEMM's: results are bit-identical to it.
+__device__ __forceinline__ void glds16_hidden_v(const void* src, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+template <class T, int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const KArgs g) {
+  using elem = typename T::elem;
+  using vec8 = typename T::vec8;
+  constexpr int TH = 8, TW = 16, HWID = TW + 2, HPIX = (TH + 2) * HWID;
+  constexpr int RING = 2;                               // fragment sets in flight (3 = two steps ahead: 16 more registers)
+  constexpr int PIECES = (HPIX + 7) / 8, HBUF = PIECES * 1024, NJ = (PIECES + 3) / 4;   // 180 px -> 23 pieces of 8 rows x 128 B; 6 copies per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];                 // 2 x HBUF | bias [64] f32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g4 = lane >> 4, pg = wave >> 1, chh = wave & 1;
+  const elem* X = (const elem*)g.X;
+  // this wave's weight slice -> registers: fragment (tap, ks, ni) = rows 32 chh + 16 ni + li, K = 64 tap + 32 ks + 8 g4 .. +7
+  vec8 wf[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        wf[tap][ks][ni] = *(const vec8*)((const elem*)g.W + (size_t)(32 * chh + 16 * ni + li) * g.ldw + 64 * tap + 32 * ks + 8 * g4);
+  if (tid < 64) ((float*)(smem + 2 * HBUF))[tid] = g.bias[tid];
+
+  const int tiles_x = (g.Wout + TW - 1) / TW, tiles_y = (g.Hout + TH - 1) / TH, tpi = tiles_x * tiles_y;
+  const int ntiles = (g.M / (g.Hout * g.Wout)) * tpi;
+  // LDS-DMA copy j of this wave = piece 4 j + wave = halo pixels 8 (4 j + wave) + (lane >> 3), physical chunk lane & 7 = logical
+  // chunk (lane & 7) ^ (pixel & 7).  voff[j]: byte offset of that source chunk from the tile's first halo pixel (tile-invariant)
+  unsigned voff[NJ];
+  const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int h = 8 * (4 * j + wave) + srow, hy = h / HWID, hx = h - hy * HWID;
+    voff[j] = h < HPIX ? (unsigned)(((hy * g.Wd + hx) * g.ldx + schunk * 8) * 2) : 0u;        // (rows past the halo: any valid address)
+  }
+  auto issue_halo = [&](int tile, int buf) {
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+    char* dst = smem + buf * HBUF;
+    if (y0 >= 0 && x0 >= 0 && y0 + TH + 2 <= g.H && x0 + HWID <= g.Wd) {      // the whole halo lies inside the map (uniform)
+      const char* base = (const char*)(X + (((size_t)n * g.H + y0) * g.Wd + x0) * g.ldx);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (4 * j + wave < PIECES) glds16_hidden_s(base, voff[j], dst + (4 * j + wave) * 1024);
+    } else {
+      const elem* img = X + (size_t)n * g.H * g.Wd * g.ldx;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (4 * j + wave < PIECES) {
+          const int h = 8 * (4 * j + wave) + srow, hy = h / HWID, hx = h - hy * HWID;
+          const int iy = y0 + hy, ix = x0 + hx;
+          const bool ok = h < HPIX && iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
+          const elem* src = ok ? img + ((size_t)iy * g.Wd + ix) * g.ldx + schunk * 8 : (const elem*)g.zeros;
+          glds16_hidden_v(src, dst + (4 * j + wave) * 1024);
+        }
+    }
+  };
+  // fragment read addresses: pixel row (4 pg + mi + ky) * 18 + kx + li of the halo, chunk (4 ks + g4) ^ (row & 7); row & 7 =
+  // (li + m) & 7 with m = (2 (mi + ky) + kx) & 7 known at compile time (4 pg * 18 = 0 mod 8), and (li + m + 4) & 7 flips the
+  // key's bit 2 exactly as ks = 1 flips the chunk's: faddr[(m + 4 ks) & 7] + the compile-time row offset addresses every fragment
+  unsigned faddr[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    faddr[m] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
+               (unsigned)(((4 * pg) * HWID + li) * 128 + ((g4 ^ ((li + m) & 7)) << 4));
+
+  const unsigned yoff = (unsigned)((li * g.ldc + (g4 & 1) * 16 + (g4 >> 1) * 8) * 2);   // output: pixel li of a row, this lane's 8 channels
+  int tile = blockIdx.x, buf = 0;
+  bool whole = false;
+  if (tile < ntiles) issue_halo(tile, 0);
+  // the weight loads complete HERE (hipcc would otherwise wait for them one by one inside the tile loop, with counts that also
+  // cover -- and so serialise -- the halo copies and the stores)
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(wf[tap][ks][ni]));
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    // this tile's halo (issued a tile ago) has landed; the previous epilogue's stores (the newest four) may stay in flight
+    if (whole) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (also the first tile: `whole` starts false)
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; everyone is done reading the other buffer
+    if (tile + (int)gridDim.x < ntiles) issue_halo(tile + gridDim.x, buf ^ 1);
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // 18 steps (tap, ks) of 4 fragment reads + 8 MFMAs.  The reads are issued from inline asm TWO steps ahead into a ring of three
+    // fragment sets and waited for by count (LDS operations retire in order): left to hipcc every read sinks to just before its
+    // first use and the MFMAs wait out the LDS latency; fully hoisted they spill.  The wait statement names the registers it
+    // releases as read-write operands, so no MFMA that reads them can be scheduled above it.
+    vec8 xr[RING][4];
+    auto rd = [&](auto sc) {
+      constexpr int s = decltype(sc)::value, tap = s >> 1, ks = s & 1, r = s % RING, ky = tap / 3, kx = tap % 3;
+      vec8 (&x)[4] = xr[r];                             // (asm operands inside a generic lambda must be named through a local)
+      unsigned (&fa)[8] = faddr;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[0]) : "v"(fa[(2 * (0 + ky) + kx + 4 * ks) & 7]), "n"(((0 + ky) * HWID + kx) * 128));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[1]) : "v"(fa[(2 * (1 + ky) + kx + 4 * ks) & 7]), "n"(((1 + ky) * HWID + kx) * 128));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[2]) : "v"(fa[(2 * (2 + ky) + kx + 4 * ks) & 7]), "n"(((2 + ky) * HWID + kx) * 128));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[3]) : "v"(fa[(2 * (3 + ky) + kx + 4 * ks) & 7]), "n"(((3 + ky) * HWID + kx) * 128));
+    };
+    auto step = [&](auto sc) {
+      constexpr int s = decltype(sc)::value, r = s % RING, AHEAD = RING - 1;
+      if constexpr (s + AHEAD < 18) rd(std::integral_constant<int, s + AHEAD>{});
+      vec8 (&x)[4] = xr[r];
+      constexpr int newer = (18 - 1 - s < AHEAD ? 18 - 1 - s : AHEAD) * 4;       // reads of later steps that may stay in flight
+      if constexpr (newer == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+      else if constexpr (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = T::mfma(wf[s >> 1][s & 1][ni], xr[r][mi], acc[mi][ni]);
+    };
+    rd(std::integral_constant<int, 0>{});
+    if constexpr (RING == 3) rd(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+    step(std::integral_constant<int, 15>{}); step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
+    // epilogue: + bias, activation, 16-bit; the two channel tiles -> 8 consecutive channels per lane by one lane swap per register
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int ox = tx * TW + li;
+    whole = (ty + 1) * TH <= g.Hout && (tx + 1) * TW <= g.Wout;
+    char* ytile = (char*)g.C + ((((size_t)n * g.Hout + ty * TH + 4 * pg) * g.Wout + tx * TW) * g.ldc + 32 * chh) * 2;
+    f32x4_t bv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bv[h] = *(const f32x4_t*)(smem + 2 * HBUF + (32 * chh + 16 * h + 4 * g4) * 4);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int oy = ty * TH + 4 * pg + mi;
+      unsigned pk[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4_t a = acc[mi][h], bb = bv[h];
+        typename T::vec4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = __fadd_rn(a[q], bb[q]);
+          if (ACT == 1) v = silu(v);
+          if (ACT == 2) v = fmaxf(v, 0.f);
+          o[q] = (elem)v;
+        }
+        const u32x2 w = __builtin_bit_cast(u32x2, o);
+        pk[h][0] = w[0]; pk[h][1] = w[1];
+      }
+      const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+      const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+      if (whole || (ox < g.Wout && oy < g.Hout)) {      // uniform row base + this lane's tile-invariant 32-bit offset (from asm:
+        const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};   // hipcc would add them into a 64-bit register pair per store)
+        const char* yrow = ytile + (size_t)mi * g.Wout * g.ldc * 2;
+        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");
+      }
+    }
+    {                                                  // the fragment addresses follow the halo buffer
+      const unsigned d = buf ? (unsigned)-HBUF : (unsigned)HBUF;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) faddr[m] += d;
+    }
+  }
+}
+
+int conv_c64_tiles(const KArgs& g) { return (g.M / (g.Hout * g.Wout)) * ((g.Wout + 15) / 16) * ((g.Hout + 7) / 8); }
+
+template <class T, int ACT>
+int launch_conv_c64(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 2 * 23 * 1024 + 256;
+  auto kern = conv3x3_c64_kernel<T, ACT>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_conv2d_nhwc: cannot raise the dynamic LDS limit")) return rc;
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int ntiles = conv_c64_tiles(g);
+  const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;                       // two workgroups per CU (registers: 2 waves per SIMD)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, g);
+  return hm_check_launch("hm_conv2d_nhwc (3x3, 64 -> 64)");
+}
+
+// the shapes the direct kernels are built for; everything else (and HM_OPT_CONV_DIRECT = 1) takes the implicit GEMM
 template <class T>
 int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
   taken = false;
@@ -2142,6 +2351,13 @@ int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
     return HM_OK;
   const int cin = 1 << g.cin_log2;
   taken = true;
+  // 3x3 stride 1, 64 -> 64, when every one of the 512 persistent workgroups gets at least two 8 x 16 tiles (its weight slice is
+  // loaded into registers once per workgroup): 16 frames, 192 x 320: 138 -> 79 us; 96 x 160 (3.75 tiles each): 40.4 -> 30.5 us;
+  // 48 x 80 (480 tiles, not taken): 16.8 -> 18.2 us.  The two kernels agree to the bit, so the choice may depend on the batch.
+  // (32-bit byte offsets inside one tile's halo: 10 rows of the input map)
+  if (cin == 64 && g.N == 64 && g.stride == 1 && g.pad == 1 && hm_option(HM_OPT_CONV_DIRECT) != 2 && (size_t)12 * g.Wd * g.ldx * 2 < (1ull << 31) &&
+      (hm_option(HM_OPT_CONV_DIRECT) == 3 || conv_c64_tiles(g) >= 1024))
+    return launch_conv_c64<T, 1>(g, s);
   // Measured per layer, 16 frames of 1080p (tools/prof_yolo.py): 3(8) -> 32: 192 -> 93 us (one frame 18 -> 11.5); 32 -> 64 stride 2:
   // 128 -> 134 and 64 -> 64: 143 -> 161 -- with 9 / 18 K-steps of four dependent global loads each and two waves per SIMD the
   // direct form is bound by load latency there (it would need a ring of fragments many K-steps deep): only the first layer takes it.

@@ -118,6 +118,35 @@ def test_conv_direct_stem_kernel_equals_the_implicit_gemm(Ci, Co, s, H, W, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,H,W", [(2, 8, 16), (1, 24, 48), (3, 19, 37), (2, 5, 70), (1, 40, 16), (16, 96, 160)])
+def test_conv_3x3_64_to_64_kernel_equals_the_implicit_gemm(n, H, W, dt):
+    """Round 3: 3x3 stride-1 64 -> 64 convolutions (the second stem layer and the 3x3s of the first two E-ELAN stages) run on
+    conv3x3_c64_kernel: weights resident in registers, the 10 x 18 pixel halo of an 8 x 16 tile staged once per tile by LDS-DMA
+    (double-buffered across the tiles of a persistent workgroup), one barrier per tile, counted waits for LDS reads and stores.
+    Same K order, MFMA and epilogue arithmetic as the implicit GEMM: the bytes must be equal to it (HM_OPT_CONV_DIRECT = 1
+    selects the implicit GEMM) on maps that are whole tiles, maps that overhang them on either side, one tile, more tiles than
+    workgroups (16 x 96 x 160: 1920 tiles for 512 workgroups), input and output as channel slices of wider buffers; and both
+    match torch."""
+    x = synth.uniform("cx", (n, 64, H, W), 1.0, seed=H + W).to(dt).float()
+    w = synth.uniform("cw", (64, 64, 3, 3), (3.0 / (64 * 9)) ** 0.5, seed=7).to(dt).float()
+    b = synth.uniform("cb", (64,), 0.3, seed=3)
+    with L.option(L.HM_OPT_CONV_DIRECT, 3):                                      # 3: at any size (by default from 1024 tiles up)
+        direct = _conv_gpu(x, w, b, 3, 1, act=True, dt=dt, ld_extra=64, y_extra=192)
+    if n == 16:
+        assert torch.equal(direct, _conv_gpu(x, w, b, 3, 1, act=True, dt=dt, ld_extra=64, y_extra=192))     # the default takes it here
+    with L.option(L.HM_OPT_CONV_DIRECT, 1):
+        gemm = _conv_gpu(x, w, b, 3, 1, act=True, dt=dt, ld_extra=64, y_extra=192)
+    with L.option(L.HM_OPT_CONV_DIRECT, 2):                                      # 2: the stem kernel only
+        gemm2 = _conv_gpu(x, w, b, 3, 1, act=True, dt=dt, ld_extra=64, y_extra=192)
+    assert torch.equal(direct, gemm)
+    assert torch.equal(gemm2, gemm)
+    if n * H * W <= 4096:
+        ref = F.silu(F.conv2d(x.double(), w.double(), b.double(), stride=1, padding=1)).float()
+        ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        np.testing.assert_allclose(direct.numpy(), ref.numpy(), atol=2e-3, rtol=2 * ulp)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_conv_split_k_exact_and_close(dt):
     """Split-K convolution (hm_conv_args.splitk_ws: few output tiles, long K -- the 12x20 / 24x40 maps of the YOLOv7 neck):
     fp32 partial slabs per K range, added in order by the reduce kernel, then bias + SiLU.  Exact on integer data for 2, 4 and

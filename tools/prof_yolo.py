@@ -1,6 +1,6 @@
 """Per-layer table of the YOLOv7 convolutions (hipEvent pairs per launch): for F frames of 1080p in one batched pass, every
 conv launch in network order with M, N, K, tile rows / columns, time and TFLOP/s, then the totals by kernel family.
-Env: FUSE=0 (no E-ELAN pair fusion), SPLITK_WS=0 (no split-K scratch), CONV_TILE=1..6 (force a tile), CONV_SPLITK=1 (never split).
+Env: FUSE=0 (no E-ELAN pair fusion), SPLITK_WS=0 (no split-K scratch), CONV_TILE=1..6 (force a tile), CONV_SPLITK=1 (never split), CONV_DIRECT=1 / 2 (no direct kernels / the stem's only).
 Usage: python tools/prof_yolo.py [frames=16] [reps=3]      (rocprofv3 --kernel-trace --stats -- python3 tools/prof_yolo.py 16)"""
 import os, sys, collections, torch
 sys.path.insert(0, ".")
@@ -17,6 +17,7 @@ eng.fuse_pairs = os.environ.get("FUSE", "1") == "1"
 eng.split_k = os.environ.get("SPLITK_WS", "1") == "1"
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_TILE, int(os.environ.get("CONV_TILE", 0))))       # 1..6: force one tile for every layer
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_SPLITK, int(os.environ.get("CONV_SPLITK", 0))))   # 1: never split
+L.check(L.load().hm_set_option(L.HM_OPT_CONV_DIRECT, int(os.environ.get("CONV_DIRECT", 0))))   # 1: implicit GEMM everywhere, 2: direct stem only
 frames = [synth.frame_u8(1080, 1920, seed=i).cuda() for i in range(F)]
 for _ in range(3):
     eng.forward(frames)
