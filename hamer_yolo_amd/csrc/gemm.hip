@@ -1358,6 +1358,13 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   }
 }
 
+// Default persistent grid: one workgroup per CU on all but ONE CU of every XCD (248 of 256; see launch_px), unless all 256 save
+// a whole round of tiles (1020 tiles = fc1 at 68 hands: 4 rounds instead of 5).
+int px_default_grid(int tiles, int cus) {
+  const int g248 = cus >= 64 ? cus - 8 : cus;
+  return (tiles + cus - 1) / cus < (tiles + g248 - 1) / g248 ? cus : g248;
+}
+
 template <class T, int EPI>
 int launch_px(const KArgs& g, hipStream_t s) {
   constexpr int LDS = 5 * 256 * 128;
@@ -1384,9 +1391,11 @@ int launch_px(const KArgs& g, hipStream_t s) {
   // quantisation: a 256-workgroup persistent kernel needs every CU of the chip at once, and whichever CU is late (the previous
   // kernel's last waves, the dispatcher) delays one workgroup's whole run of tiles.  With two batches in flight the other
   // stream filled that hole already (17.55 ms either way).
-  int want = g_px_grid > 0 ? g_px_grid : (cus >= 64 ? cus - 8 : cus);
+  int want = g_px_grid > 0 ? g_px_grid : px_default_grid(tiles, cus);
   if (want > cus) want = cus;
-  const int grid = (tiles < want ? tiles : want) & ~7;             // a multiple of the 8 XCDs
+  // a multiple of the 8 XCDs, rounded UP when there are fewer tiles than workgroups (a workgroup without a tile returns at once;
+  // rounded down, 180 tiles on 176 workgroups were two rounds: qkv at 16 hands 67 us against 43 for the 128 x 128 tile)
+  const int grid = tiles < want ? ((tiles + 7) & ~7) : (want & ~7);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);
   return hm_check_launch("hm_gemm");
 }
@@ -1966,7 +1975,7 @@ bool variant_ok(int v) {
   return false;
 }
 
-int pick_variant(const KArgs& g) {
+int pick_variant(const KArgs& g, int epilogue) {
   if (g_variant == -2) {
     const char* e = getenv("HM_GEMM_VARIANT");     // tuning runs only; an unknown or ablation id is ignored, never obeyed
     const int v = e ? atoi(e) : -1;
@@ -1974,19 +1983,40 @@ int pick_variant(const KArgs& g) {
   }
   if (g_variant >= 0) return g_variant;
   if (g.M < 1024 || g.N < 512) return 0;
-  // the 256x256 tile only when its tiles fill whole rounds of the 256 CUs: at 16-32 hands proj / fc2 have 60-120 of them
-  // and qkv 180-360, and the 128x128 tile (2 workgroups per CU) is 20-60 % faster over the forward
-  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256), rounds = (tiles + 255) / 256;
-  if (tiles * 100 < rounds * 256 * 85) return 0;
-  return 26;     // persistent 256x256 (gemm_px_kernel) for the 16-bit store epilogues on whole tiles; otherwise the
-                 // one-tile kernel with X two K-steps ahead (gemm_x3_kernel, variant 24), else the variant-10 tile.
-                 // Measured at B = 64, fp16 (interleaved A/B, us per launch): fc1 172 (24) / 164 (25: 256x320, 3.0 rounds
-                 // and 10 % fewer operand bytes per flop) / 162 (26); kv 181 / 180 / 174; qkv 119 / 143 / 119.
+  const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+  if (hm_option(HM_OPT_GEMM_TILE_RULE) == 1) {
+    // round 2's rule: the 256x256 tile only when its tiles fill whole rounds of the 256 CUs to 85 %
+    const int rounds = (tiles + 255) / 256;
+    return tiles * 100 < rounds * 256 * 85 ? 0 : 26;
+  }
+  // Round 3: whichever tile finishes sooner under a small model fitted to per-shape measurements at 16..96 hands
+  // (tools/gpu/r03_s.sh, profiles/r03_gemm_tile_rule_sweep.log).  The 256 x 256 kernels take whole rounds of equal tiles --
+  // the persistent gemm_px_kernel (16-bit store / GELU epilogues) on its grid of 248 or 256, the one-tile kernels (gemm_x3r /
+  // gemm_x3: fp32 residual and the rest) one per CU -- at ~1000 TFLOP/s of a full round; the 128 x 128 tile has 512 slots that
+  // refill as workgroups finish (fractional rounds, at least one) at ~700 (store epilogues) / ~520 (fp32 residual) of the same
+  // unit (isolated launches put the residual shapes at 560; with two forwards in flight the other stream fills a big tile's idle
+  // last round, and 72-80 hands ran 1-6 % faster with the big tile there).  Round 2's 85 % rule sent 40, 48, 56, 72 and 76 hands to the small tile for fc1 / qkv (fc1 at 72 hands: 1080 tiles =
+  // 84 % of five rounds) and cost 9-15 % of the whole forward there (tools/probes/forward_vs_batch.py); 16-32 hands keep the
+  // small tile for proj / fc2 (60-120 big tiles) under both rules.
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const bool persistent = epilogue == HM_EPI_STORE || epilogue == HM_EPI_GELU;
+  const int big_slots = persistent ? px_default_grid(tiles, cus) : cus;
+  const int small_tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+  const double big_rounds = (double)((tiles + big_slots - 1) / big_slots);
+  double small_rounds = (double)small_tiles / (2.0 * cus);
+  if (small_rounds < 1.0) small_rounds = 1.0;
+  const double t_big = big_rounds / 1000.0, t_small = small_rounds * 0.5 / (epilogue == HM_EPI_RESID_F32 ? 520.0 : 700.0);
+  return t_big <= t_small ? 26 : 0;
+  // 26: persistent 256x256 (gemm_px_kernel) for the 16-bit store epilogues on whole tiles; otherwise the one-tile kernel with X
+  // two K-steps ahead (gemm_x3_kernel / gemm_x3r_kernel, variant 24), else the variant-10 tile.  Measured at B = 64, fp16
+  // (interleaved A/B, us per launch): fc1 172 (24) / 164 (25: 256x320, 3.0 rounds and 10 % fewer operand bytes per flop) / 162
+  // (26); kv 181 / 180 / 174; qkv 119 / 143 / 119.
 }
 
 template <class T>
 int launch_gemm_epi(const KArgs& g, int epilogue, hipStream_t s) {
-  const int v = pick_variant(g);
+  const int v = pick_variant(g, epilogue);
   switch (epilogue) {
     case HM_EPI_STORE: return launch_gemm<T, HM_EPI_STORE>(g, v, s);
     case HM_EPI_GELU: return launch_gemm<T, HM_EPI_GELU>(g, v, s);

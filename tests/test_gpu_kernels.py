@@ -65,6 +65,30 @@ def test_gemm_tile_variants_exact(variant):
     _tile_variant_exact(variant)
 
 
+@pytest.mark.parametrize("hands", [16, 17, 23, 40, 45, 68, 72])
+def test_gemm_tile_rule_exact_at_every_batch_size(hands):
+    """Round 3: pick_variant's rate model (HM_OPT_GEMM_TILE_RULE = 0; 1 = round 2's 85 % rule) and the persistent kernel's grid
+    (rounded UP to the 8 XCDs when there are fewer tiles than workgroups: 180 tiles -> 184 workgroups, four of them idle; all
+    256 CUs when that saves a round) at the ViT-H row counts of 16..72 hands: whatever tile is chosen, exact-integer data must
+    come back bit-exact, for the three epilogues the choice depends on, and both rules agree."""
+    M = hands * 192
+    lib = L.load()
+    for (N, K, epi) in ((3840, 128, L.HM_EPI_STORE), (1280, 192, L.HM_EPI_RESID_F32), (5120, 128, L.HM_EPI_STORE)):
+        x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+        w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()
+        bias = (torch.arange(N) % 9 - 4).float()
+        ref = x @ w.t() + bias
+        r = ((torch.arange(M * N).reshape(M, N) % 11) - 5).float() if epi == L.HM_EPI_RESID_F32 else None
+        outs = []
+        for rule in (0, 1):
+            with L.option(L.HM_OPT_GEMM_TILE_RULE, rule):
+                out = ops.gemm(x.to(DEV, torch.float16), w.to(DEV, torch.float16), bias.to(DEV), epi,
+                               resid=r.to(DEV) if r is not None else None)
+            outs.append(out.float().cpu())
+        assert torch.equal(outs[0], ref + (r if r is not None else 0)), (hands, N, K, epi)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_set_variant_accepts_shipped_tiles_only():
     """The experimental tiles (1-9, 11, 12, 21-23, 25, 28, 29) and the wrong-result ablations live in libhamer_hip_abl.so
     (python -m hamer_yolo_amd.build --ablations); the product refuses them instead of silently running something else."""
