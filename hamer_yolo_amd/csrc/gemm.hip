@@ -365,17 +365,26 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
   }
 }
 
-template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g) {
-  constexpr int NW = WM * WN;
+// WK > 1 (round 3, convolutions on the small maps): the workgroup carries WK copies of the WM x WN wave grid, each with its own
+// LDS ring; at every step group kg works on K tile kt * WK + kg, so the serial chain of K-steps -- what a layer with 30-120 row
+// tiles is bound by -- is WK times shorter with WK times the bytes in flight, and no partial sums leave the CU: after the loop
+// the groups kg > 0 hand their accumulators to group 0 through LDS (added in the order kg = 1, 2, ..: deterministic).
+// KDUAL (WK = 1): the SAME summation order in one group of waves -- even K tiles into one accumulator set, odd ones into a
+// second, added at the end -- so that a layer may run on either form, by launch size, with bit-identical results.
+template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0, int WK = 1, bool KDUAL = false>
+__global__ __launch_bounds__(64 * WM * WN * WK, WK > 1 ? 1 : 2) void gemm_tn_kernel(const KArgs g) {
+  constexpr int NWG = WM * WN;                        // waves of one K group
+  constexpr int NW = NWG * WK;
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
   constexpr int ROWB = BK * 2;                        // bytes per tile row in LDS (128 or 64)
   constexpr int CH = BK / 8;                          // 16-byte chunks per row
   constexpr int RPI = 1024 / ROWB;                    // rows covered by one 1-KiB LDS-DMA instruction
-  constexpr int XI = BM / NW / RPI, WI = BN / NW / RPI;   // staging instructions per wave and K-tile
+  constexpr int XI = BM / NWG / RPI, WI = BN / NWG / RPI;   // staging instructions per wave and K-tile
   static_assert(BK == 64 || BK == 32, "BK is 64 or 32");
   static_assert(!CONV || BK == 64, "the implicit-GEMM loader is written for BK = 64");
-  static_assert(BM % (NW * RPI) == 0 && BN % (NW * RPI) == 0, "tile rows must split into whole DMA pieces per wave");
+  static_assert(BM % (NWG * RPI) == 0 && BN % (NWG * RPI) == 0, "tile rows must split into whole DMA pieces per wave");
+  static_assert(WK == 1 || (CONV && SCHED == 0), "K groups: written for the convolution flavour");
+  static_assert(!KDUAL || (WK == 1 && CONV && SCHED == 0), "the two-accumulator form is the one-group twin of WK = 2");
   constexpr int XTILE_BYTES = BM * BK * 2, WTILE_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = XTILE_BYTES + WTILE_BYTES;
   constexpr int LOADS = XI + WI;
@@ -384,7 +393,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   using elem = typename T::elem;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = WK > 1 ? wave_all / NWG : 0, wave = WK > 1 ? wave_all % NWG : wave_all;      // K group, wave within the group
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   int tm, tn;
   const int wgid = xcd_remap(blockIdx.x, gridDim.x);
@@ -427,12 +437,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     wsrc[i] = W + (size_t)gn * g.ldw + chunk * 8;
   }
 
-  const int nk = EPI == HM_EPI_F32 ? g.K / BK / g.ksplit : g.K / BK;
-  const int kt0 = split * nk;                           // split-K: this workgroup's K range starts kt0 tiles in
+  const int nk_all = EPI == HM_EPI_F32 ? g.K / BK / g.ksplit : g.K / BK;
+  const int kt0 = split * nk_all;                       // split-K: this workgroup's K range starts kt0 tiles in
+  const int nk = nk_all / WK;                           // steps of the loop (host: nk_all % WK == 0); group kg takes tile kt * WK + kg
   auto stage = [&](int buf, int kt) {
     if (SCHED == 93) return;                            // ablation: no global loads at all
-    char* lx = smem + buf * STAGE_BYTES + wave * XI * 1024;
-    char* lw = smem + buf * STAGE_BYTES + XTILE_BYTES + wave * WI * 1024;
+    char* lx = smem + (kg * STAGES + buf) * STAGE_BYTES + wave * XI * 1024;
+    char* lw = smem + (kg * STAGES + buf) * STAGE_BYTES + XTILE_BYTES + wave * WI * 1024;
+    if (WK > 1) kt = kt * WK + kg;
     if (CONV) {
       const int k = (kt0 + kt) * BK + chunk * 8;
       const int tap = k >> g.cin_log2, ci = k & ((1 << g.cin_log2) - 1);
@@ -461,9 +473,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
   // fragment reads: row = tile_row + (lane&15); 16-B chunk = ks*4 + (lane>>4), swizzled with the staging key
   const int frow = lane & 15, fsw = BK == 64 ? (lane & 7) : ((lane >> 2) & 3), fch = lane >> 4;
   // one K sub-step (32 deep): fragment reads + NI x MI MFMAs
-  auto substep = [&](int buf, int ks) {
+  auto substep = [&](int buf, int ks, f32x4_t (&acc)[NI][MI]) {
     if (SCHED == 92) return;                            // ablation: LDS-DMA fill only
-    const char* lx = smem + buf * STAGE_BYTES;
+    const char* lx = smem + (kg * STAGES + buf) * STAGE_BYTES;
     const char* lw = lx + XTILE_BYTES;
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
     vec8 wf[NI], xf[MI];
@@ -513,8 +525,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     if (s < nk) stage(s, s);
   // deferred-LN consumer: (mean, rstd) of this tile's rows from the producer's 64-column partials, kept in LDS past
   // the ring; the K loop's barriers order these writes before the epilogue reads
-  constexpr int SKB = NW > 8 ? 8 : 16;                 // sixteen waves: 8 KB of epilogue staging each
-  constexpr int RING_BYTES = STAGES * STAGE_BYTES, EPI_BYTES = NW * epi_stage_bytes(MI, NI, SKB);
+  constexpr int SKB = NWG > 8 ? 8 : 16;                // sixteen waves: 8 KB of epilogue staging each
+  constexpr int RING_BYTES = WK * STAGES * STAGE_BYTES, EPI_BYTES = NWG * epi_stage_bytes(MI, NI, SKB);
+  static_assert(WK == 1 || EPI_BYTES + (WK - 1) * NWG * MI * NI * 1024 <= RING_BYTES, "epilogue staging + the K groups' accumulators fit in the rings");
   float2* rowstat = (float2*)(smem + (RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES));
   float* colvec = (float*)(rowstat + BM);              // [2][BN]: bias (or zeros) | ln_gamma or ln_colsum
   for (int c = tid; c < BN; c += 64 * NW) {
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     for (int r = tid; r < BM; r += 64 * NW) rowstat[r] = ((const float2*)g.ln_stats)[min(m0 + r, g.M - 1)];   // (mean, rstd) per row
   }
   int rd = 0, wrb = STAGES - 1;                        // ring slots: read tile kt, write tile kt+STAGES-1
-  for (int kt = 0; kt < nk; ++kt) {
+  auto kstep = [&](int kt, f32x4_t (&acc)[NI][MI]) {
     // tile kt must have landed: in steady state the STAGES-2 newer tiles may still be in flight
     if (SCHED != 94 && SCHED != 95) {                  // (ablations 94 / 95: nobody waits for the copies; 95: no barrier either)
       if (kt + STAGES - 2 < nk) wait_vmcnt<LOADS * (STAGES - 2)>();
@@ -538,18 +551,53 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_tn_kernel(const KArgs g)
     if (SCHED <= 1) {                                  // loads first, then the whole tile
       if (more) stage(wrb, kt + STAGES - 1);
 #pragma unroll
-      for (int ks = 0; ks < BK / 32; ++ks) substep(rd, ks);
+      for (int ks = 0; ks < BK / 32; ++ks) substep(rd, ks, acc);
     } else {                                           // first sub-step, then the loads, then the rest
-      substep(rd, 0);
+      substep(rd, 0, acc);
       if (more) stage(wrb, kt + STAGES - 1);
 #pragma unroll
-      for (int ks = 1; ks < BK / 32; ++ks) substep(rd, ks);
+      for (int ks = 1; ks < BK / 32; ++ks) substep(rd, ks, acc);
     }
     rd = rd + 1 == STAGES ? 0 : rd + 1;
     wrb = wrb + 1 == STAGES ? 0 : wrb + 1;
+  };
+  if constexpr (KDUAL) {                               // (host: nk even)
+    f32x4_t acc2[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc2[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; kt += 2) {
+      kstep(kt, acc);
+      kstep(kt + 1, acc2);
+    }
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] += acc2[a][b];
+  } else {
+    for (int kt = 0; kt < nk; ++kt) kstep(kt, acc);
   }
 
   __builtin_amdgcn_s_barrier();                        // every wave is done reading the ring: reuse it for the epilogue
+  if constexpr (WK > 1) {
+    // accumulators of the K groups 1.. -> group 0, through LDS behind the epilogue staging: [kg - 1][wave][ni][mi][lane] x 16 B
+    f32x4_t* red = (f32x4_t*)(smem + EPI_BYTES);
+    if (kg > 0) {
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) red[((((kg - 1) * NWG + wave) * NI + a) * MI + b) * 64 + lane] = acc[a][b];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int q = 1; q < WK; ++q)
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] += red[((((q - 1) * NWG + wave) * NI + a) * MI + b) * 64 + lane];
+  }
   if (SCHED == 96 || SCHED == 98) {                     // ablation: no epilogue (keep the accumulators alive)
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -1868,16 +1916,18 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
   fin[m] = float2{mean, 1.0f / sqrtf(fmaxf(b * invD - mean * mean, 0.f) + eps)};
 }
 
-template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0>
+template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0, int WK = 1, bool KDUAL = false>
 int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
-  constexpr int RING = STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI, WM * WN > 8 ? 8 : 16);
+  constexpr int RING = WK * STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI, WM * WN > 8 ? 8 : 16);
   constexpr int LDS = (RING > EPIB ? RING : EPIB) + BM * 8 + BN * 8;     // + row statistics + column vectors
-  auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED>;
+  static_assert(LDS <= 160 * 1024, "fits the CU's LDS");
+  if ((WK > 1 || KDUAL) && (g.K / BK / (EPI == HM_EPI_F32 ? g.ksplit : 1)) % 2 != 0) return hm_set_error(HM_ERR_ARG, "gemm: K tiles do not split over the K groups");
+  auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED, WK, KDUAL>;
   static HmLdsOnce lds_once;
   if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == HM_EPI_F32 ? g.ksplit : 1);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), LDS, s, g);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN * WK), LDS, s, g);
   return hm_check_launch(what);
 }
 
@@ -2400,11 +2450,15 @@ int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
 // eight-wave 256-row tiles of the ViT GEMM (256 x 256 / 128 / 64: half the operand bytes per flop) for the layers whose output
 // has enough of them to fill the chip, and split-K (below) for the layers that have too few tiles of any shape.
 enum { CT_128x128 = 0, CT_128x64 = 1, CT_128x32 = 2, CT_256x128 = 3, CT_256x256 = 4, CT_256x64 = 5,
-       CT_128x32_D = 6, CT_128x64_D = 7, CT_128x128_D = 8, CT_COUNT = 9 };      // _D: deep ring (4 / 4 / 3 stages) for lone workgroups
+       CT_128x32_D = 6, CT_128x64_D = 7, CT_128x128_D = 8,                      // _D: deep ring (4 / 4 / 3 stages) for lone workgroups
+       CT_128x32_K2 = 9, CT_128x64_K2 = 10, CT_128x128_K2 = 11,                 // _K2: two K groups of four waves (3 / 3 / 2 stages each)
+       CT_128x32_P2 = 12, CT_128x64_P2 = 13, CT_128x128_P2 = 14, CT_COUNT = 15 }; // _P2: one group, two accumulator sets -- the K2 order
 constexpr int ct_bm(int t) { return (t >= CT_256x128 && t <= CT_256x64) ? 256 : 128; }
 constexpr int ct_bn(int t) {
-  return (t == CT_128x128 || t == CT_256x128 || t == CT_128x128_D) ? 128 : (t == CT_256x256 ? 256 : ((t == CT_128x32 || t == CT_128x32_D) ? 32 : 64));
+  return (t == CT_128x128 || t == CT_256x128 || t == CT_128x128_D || t == CT_128x128_K2 || t == CT_128x128_P2) ? 128
+         : (t == CT_256x256 ? 256 : ((t == CT_128x32 || t == CT_128x32_D || t == CT_128x32_K2 || t == CT_128x32_P2) ? 32 : 64));
 }
+constexpr bool ct_k2(int t) { return t >= CT_128x32_K2 && t <= CT_128x128_P2; }      // the tiles with the two-group summation order
 
 int conv_tiles(const KArgs& g, int t) { return ((g.M + ct_bm(t) - 1) / ct_bm(t)) * ((g.N + ct_bn(t) - 1) / ct_bn(t)); }
 
@@ -2415,12 +2469,32 @@ int conv_tiles(const KArgs& g, int t) { return ((g.M + ct_bm(t) - 1) / ct_bm(t))
 //  * otherwise the 128-row tiles, two to four workgroups per CU, narrowed while most CUs would stay without a tile;
 //  * when even the narrow tile leaves at most one workgroup per CU, nothing hides the global -> LDS round trip of a two-stage
 //    ring (0.8 us per 64-deep K-step measured on the 12x20 maps): those layers take the deep ring (`ks` = K ranges of split-K).
-int pick_conv_tile(const KArgs& g, int ks_hint = 1) {
+// K groups for the 12 x 20 / 24 x 40 maps.  WHETHER a layer sums its even and odd K tiles separately is, like split-K, a rule on
+// ONE image's output (the summation order changes, and a frame must get the same bytes alone and in a batch): at most 1024
+// output pixels per image and at least 8 K tiles per K range, an even number of them.  HOW it does so depends on the launch:
+// few workgroups (one frame; 16 frames of a narrow layer) take two groups of four waves with a ring each
+// (gemm_tn_kernel<..., WK = 2>: half the serial K-steps, twice the bytes in flight), many workgroups one group with two
+// accumulator sets (<..., KDUAL>: two workgroups per CU overlap each other) -- bit-identical by construction.  One frame: the
+// small-map layers -10..-30 % (0.94 ms for the whole pass instead of 1.08); 16 frames: -14..-33 % for the narrow layers, while
+// K groups everywhere cost the wide ones +10..+40 % (profiles/r03_yolo_kgroups_*.txt).  HM_OPT_CONV_KGROUPS = 1: never.
+int conv_kgroups(const KArgs& g, int ks) {
+  if (hm_option(HM_OPT_CONV_KGROUPS) == 1) return 1;
+  const int nk = g.K / 64 / (ks > 1 ? ks : 1);
+  return (g.Hout * g.Wout <= 1024 && nk >= 8 && nk % 2 == 0) ? 2 : 1;
+}
+
+int pick_conv_tile(const KArgs& g, int ks_hint = 1, int wk = 1) {
   const int forced = hm_option(HM_OPT_CONV_TILE);
-  if (forced > 0 && forced <= CT_COUNT) return forced - 1;
-  if (g.N >= 256 && conv_tiles(g, CT_256x256) >= 200) return CT_256x256;
+  if (forced > 0 && forced <= CT_COUNT && (ct_k2(forced - 1) ? wk == 2 : wk == 1)) return forced - 1;   // (a forced tile never changes the K order)
+  if (wk == 1 && g.N >= 256 && conv_tiles(g, CT_256x256) >= 200) return CT_256x256;
   int t = g.N > 64 ? CT_128x128 : (g.N > 32 ? CT_128x64 : CT_128x32);
   while (t < CT_128x32 && conv_tiles(g, t) < 192) ++t;
+  if (wk == 2) {
+    const int wgs = conv_tiles(g, t) * ks_hint;
+    const bool groups = wgs <= 128 || (ks_hint == 1 && wgs <= 256);       // few workgroups: two K groups each; else two accumulator sets
+    if (groups) return t == CT_128x128 ? CT_128x128_K2 : (t == CT_128x64 ? CT_128x64_K2 : CT_128x32_K2);
+    return t == CT_128x128 ? CT_128x128_P2 : (t == CT_128x64 ? CT_128x64_P2 : CT_128x32_P2);
+  }
   if (conv_tiles(g, t) * ks_hint <= 288 && g.K >= 4 * 64) t = t == CT_128x128 ? CT_128x128_D : (t == CT_128x64 ? CT_128x64_D : CT_128x32_D);
   return t;
 }
@@ -2437,6 +2511,12 @@ int launch_conv_tile(const KArgs& g, int t, hipStream_t s) {
     case CT_128x32_D: return launch_cfg<T, EPI, 2, 2, 4, 1, 4, true>(g, s, "hm_conv2d_nhwc");      // 4 x 20 KB
     case CT_128x64_D: return launch_cfg<T, EPI, 2, 2, 4, 2, 4, true>(g, s, "hm_conv2d_nhwc");      // 4 x 24 KB
     case CT_128x128_D: return launch_cfg<T, EPI, 2, 2, 4, 4, 3, true>(g, s, "hm_conv2d_nhwc");     // 3 x 32 KB
+    case CT_128x32_K2: return launch_cfg<T, EPI, 2, 2, 4, 1, 3, true, 64, 0, 2>(g, s, "hm_conv2d_nhwc");     // 2 x 3 x 20 KB
+    case CT_128x64_K2: return launch_cfg<T, EPI, 2, 2, 4, 2, 3, true, 64, 0, 2>(g, s, "hm_conv2d_nhwc");     // 2 x 3 x 24 KB
+    case CT_128x128_K2: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true, 64, 0, 2>(g, s, "hm_conv2d_nhwc");    // 2 x 2 x 32 KB
+    case CT_128x32_P2: return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
+    case CT_128x64_P2: return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
+    case CT_128x128_P2: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
     default: return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unknown tile");
   }
 }
@@ -2501,7 +2581,7 @@ int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStr
   int ks = (ws && g.bias && act_ok && ((((uintptr_t)ws) | ((uintptr_t)g.C)) & 15) == 0) ? conv_split_rule(g) : 1;   // (the reduce kernel stores 16 bytes per lane)
   if (ks > 1 && (size_t)ks * g.M * g.N * 4 > ws_bytes)
     return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: splitk_ws too small (hm_conv_splitk_bytes gives the size; the split must not depend on what fits)");
-  const int t = pick_conv_tile(g, ks);
+  const int t = pick_conv_tile(g, ks, conv_kgroups(g, ks));
   if (ks > 1) {
     void* y = g.C; const int ldy = g.ldc; const float* bias = g.bias;
     g.C = ws; g.ldc = g.N; g.bias = nullptr; g.ksplit = ks;

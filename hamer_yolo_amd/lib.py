@@ -15,10 +15,10 @@ LIB_PATH = os.path.join(HERE, "libhamer_hip.so")
 HM_DTYPE_BF16, HM_DTYPE_F16, HM_OUT_F32 = 0, 1, 2
 HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 3, 4
 HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU, HM_EPI_GELU_MX8 = 5, 6, 7, 8
-HM_VERSION = 301      # include/hamer_hip.h: load() refuses a library built from another header
+HM_VERSION = 302      # include/hamer_hip.h: load() refuses a library built from another header
 (HM_OPT_PX_GRID, HM_OPT_FP8P_GRID, HM_OPT_FP8_ONE_TILE, HM_OPT_FP8P_RESID, HM_OPT_TOME_NO_SPLITK,
  HM_OPT_TOME_SCALAR_ATTENTION, HM_OPT_RESID_IN_EPILOGUE, HM_OPT_CONV_TILE, HM_OPT_CONV_SPLITK, HM_OPT_PX_LDS_EPILOGUE, HM_OPT_CONV_DIRECT,
- HM_OPT_GEMM_TILE_RULE) = range(12)
+ HM_OPT_GEMM_TILE_RULE, HM_OPT_CONV_KGROUPS) = range(13)
 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HM_VERSION 301   /* round 3: hm_set_option, hm_hamer_weights.tome_r, hm_nms_workspace_bytes(n, cap) -- lib.load() checks it */
+#define HM_VERSION 302   /* round 3: hm_set_option, hm_hamer_weights.tome_r, hm_nms_workspace_bytes(n, cap) -- lib.load() checks it */
 
 enum { HM_DTYPE_BF16 = 0, HM_DTYPE_F16 = 1 };
 
@@ -98,7 +98,8 @@ enum {
   HM_OPT_PX_LDS_EPILOGUE = 9,       /* persistent GEMM epilogue: 0 = per epilogue (GELU: lane swaps, store: through LDS), 1 = always LDS, 2 = always lane swaps */
   HM_OPT_CONV_DIRECT = 10,          /* direct 3x3 kernels (3(8) -> 32 stem; 64 -> 64 stride 1): 0 = both (64 -> 64 from 1024 tiles of 8 x 16 pixels up), 1 = neither (implicit GEMM everywhere), 2 = stem only, 3 = both, 64 -> 64 at any size */
   HM_OPT_GEMM_TILE_RULE = 11,       /* tuning: 1 = round 2's GEMM tile rule (256 x 256 only from 85 % full rounds), 0 = the rate model */
-  HM_OPT_COUNT = 12
+  HM_OPT_CONV_KGROUPS = 12,         /* tuning: 1 = no K groups inside a convolution workgroup (small maps), 0 = automatic */
+  HM_OPT_COUNT = 13
 };
 int hm_set_option(int key, int value);
 int hm_get_option(int key);

@@ -91,9 +91,48 @@ def test_conv_every_tile_exact_and_equal(tile):
     x = synth.uniform("tx", (2, 128, 24, 40), 1.0, seed=3).half().float()
     w = synth.uniform("tw", (256, 128, 3, 3), 0.05, seed=4).half().float()
     b = synth.uniform("tb", (256,), 0.3, seed=5)
+    with L.option(L.HM_OPT_CONV_KGROUPS, 1):                 # (this map would take two K groups, whose tiles are tested below)
+        base = _conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16)
+        with L.option(L.HM_OPT_CONV_TILE, tile):
+            assert torch.equal(_conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16), base)
+
+
+@pytest.mark.parametrize("tile", [0, 10, 11, 12, 13, 14, 15])
+def test_conv_k_groups_exact_and_close(tile):
+    """Round 3: on the 12 x 20 / 24 x 40 maps (at most 1024 output pixels per image, >= 8 K tiles per K range) the workgroup
+    carries TWO K groups of four waves, each with its own LDS ring, that take alternate K tiles and hand their accumulators to
+    group 0 through LDS (gemm_tn_kernel<..., WK = 2>; tiles 128 x 32 / 64 / 128 `_K2`, forced as 10-12) when the launch has few
+    workgroups -- and, when it has many, on ONE group with two accumulator sets for the even and the odd K tiles (`_P2`, 13-15):
+    the same summation order, so the choice by launch size cannot change a byte.  Exact on integer data for the
+    automatic choice and for each of the six tiles forced, 3x3 and 1x1, stride 1 and 2, alone and on top of split-K
+    (K = 4608 on 12 x 20: four K ranges of 18 tiles, nine steps per group); the same bytes for every tile (one K order); on
+    random data within fp32 summation-order distance of the kernel without K groups (HM_OPT_CONV_KGROUPS = 1), and a frame gets
+    the same bytes alone and inside a batch of five (the rule looks at one image)."""
+    with L.option(L.HM_OPT_CONV_TILE, tile):
+        for (Ci, Co, k, s, H, W, ws) in ((128, 72, 3, 1, 12, 20, False), (128, 264, 3, 2, 47, 79, False), (512, 40, 1, 1, 24, 40, False),
+                                         (512, 64, 3, 1, 12, 20, True)):
+            x = (torch.arange(2 * Ci * H * W).reshape(2, Ci, H, W) % 5 - 2).float()
+            w = ((torch.arange(Co * Ci * k * k).reshape(Co, Ci, k, k) * 7 + torch.arange(Co)[:, None, None, None]) % 3 - 1).float()
+            b = (torch.arange(Co) % 7 - 3).float()
+            ref = F.conv2d(x, w, b, stride=s, padding=k // 2)
+            wsb = torch.empty(8 * 2 * H * W * Co * 4, dtype=torch.uint8, device=DEV) if ws else None
+            y = _conv_gpu(x, w, b, k, s, act=False, dt=torch.float16, ld_extra=8, y_extra=8, splitk_ws=wsb)
+            assert torch.equal(y, ref.half().float()), (tile, Ci, Co, k, s)
+            if not ws:
+                assert torch.equal(_conv_gpu(x, w, b, k, s, act=False, dt=torch.float16, out_f32=True), ref), (tile, Ci, Co, k, s)
+    x = synth.uniform("kx", (5, 256, 24, 40), 1.0, seed=3).half().float()
+    w = synth.uniform("kw", (256, 256, 3, 3), 0.03, seed=4).half().float()
+    b = synth.uniform("kb", (256,), 0.3, seed=5)
     base = _conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16)
     with L.option(L.HM_OPT_CONV_TILE, tile):
-        assert torch.equal(_conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16), base)
+        y = _conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16)
+        one = _conv_gpu(x[3:4], w, b, 3, 1, act=True, dt=torch.float16)
+    assert torch.equal(y, base) and torch.equal(one, y[3:4])
+    with L.option(L.HM_OPT_CONV_KGROUPS, 1):
+        plain = _conv_gpu(x, w, b, 3, 1, act=True, dt=torch.float16)
+    assert not torch.equal(plain, base)                       # (another summation order: some fp16 roundings move)
+    ref = F.silu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    assert (base - ref).abs().max() < 2e-3 and (plain - ref).abs().max() < 2e-3 and (base - plain).abs().max() < 2e-3
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

@@ -50,9 +50,9 @@ def test_options_are_explicit_setters_not_environment_reads(monkeypatch):
     The switches live behind hm_set_option / hm_get_option; only the two start-up tuning defaults are read from the
     environment, once."""
     lib = L.load()
-    for key in range(12):                                 # HM_OPT_COUNT
+    for key in range(13):                                 # HM_OPT_COUNT
         assert lib.hm_get_option(key) == 0
-    assert lib.hm_get_option(12) == 0 and lib.hm_set_option(12, 1) != 0
+    assert lib.hm_get_option(13) == 0 and lib.hm_set_option(13, 1) != 0
     assert lib.hm_set_option(99, 1) != 0 and lib.hm_set_option(L.HM_OPT_FP8P_GRID, 12) != 0 and lib.hm_set_option(0, -1) != 0
     with L.option(L.HM_OPT_FP8P_GRID, 40):
         assert lib.hm_get_option(L.HM_OPT_FP8P_GRID) == 40
