@@ -2118,7 +2118,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const KArgs g) {
   const int xblocks = (g.Wout + 63) / 64;
   const int groups = (g.M / g.Wout) * xblocks;          // (image, output row) pairs x 64-pixel blocks
   const elem* X = (const elem*)g.X;
-  for (int grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
+  // XCD-aware order: workgroups b, b + 8, .. share an XCD and its L2 -- give them consecutive rows, so that the three output rows
+  // that read an input row do so through one L2 (dealt round robin every XCD fetched its own copy: 3.1x the input, PMC)
+  for (int grp = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave; grp < groups; grp += gridDim.x * 4) {
     const int rowi = grp / xblocks, x0 = (grp - rowi * xblocks) * 64;
     const int n = rowi / g.Hout, oy = rowi - n * g.Hout;
     const elem* img = X + (size_t)n * g.H * g.Wd * g.ldx;
@@ -2305,7 +2307,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const KArgs g) {
                (unsigned)(((4 * pg) * HWID + li) * 128 + ((g4 ^ ((li + m) & 7)) << 4));
 
   const unsigned yoff = (unsigned)((li * g.ldc + (g4 & 1) * 16 + (g4 >> 1) * 8) * 2);   // output: pixel li of a row, this lane's 8 channels
-  int tile = blockIdx.x, buf = 0;
+  int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;     // neighbouring tiles (shared halo columns / rows) through one XCD's L2
   bool whole = false;
   if (tile < ntiles) issue_halo(tile, 0);
   // the weight loads complete HERE (hipcc would otherwise wait for them one by one inside the tile loop, with counts that also
