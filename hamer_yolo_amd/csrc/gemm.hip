@@ -2473,7 +2473,7 @@ int conv_tiles(const KArgs& g, int t) { return ((g.M + ct_bm(t) - 1) / ct_bm(t))
 //    ring (0.8 us per 64-deep K-step measured on the 12x20 maps): those layers take the deep ring (`ks` = K ranges of split-K).
 // K groups for the 12 x 20 / 24 x 40 maps.  WHETHER a layer sums its even and odd K tiles separately is, like split-K, a rule on
 // ONE image's output (the summation order changes, and a frame must get the same bytes alone and in a batch): at most 1024
-// output pixels per image and at least 8 K tiles per K range, an even number of them.  HOW it does so depends on the launch:
+// output pixels per image (4096 for Cout <= 128) and at least 8 K tiles per K range, an even number of them.  HOW it does so depends on the launch:
 // few workgroups (one frame; 16 frames of a narrow layer) take two groups of four waves with a ring each
 // (gemm_tn_kernel<..., WK = 2>: half the serial K-steps, twice the bytes in flight), many workgroups one group with two
 // accumulator sets (<..., KDUAL>: two workgroups per CU overlap each other) -- bit-identical by construction.  One frame: the
@@ -2482,7 +2482,10 @@ int conv_tiles(const KArgs& g, int t) { return ((g.M + ct_bm(t) - 1) / ct_bm(t))
 int conv_kgroups(const KArgs& g, int ks) {
   if (hm_option(HM_OPT_CONV_KGROUPS) == 1) return 1;
   const int nk = g.K / 64 / (ks > 1 ? ks : 1);
-  return (g.Hout * g.Wout <= 1024 && nk >= 8 && nk % 2 == 0) ? 2 : 1;
+  const int m_img = g.Hout * g.Wout;
+  // (48 x 80 maps too where the layer is narrow: one frame has 30 row tiles there; wide layers of that size keep the 256 x 256
+  //  tile for batched passes, which cannot hold two accumulator sets)
+  return ((m_img <= 1024 || (m_img <= 4096 && g.N <= 128)) && nk >= 8 && nk % 2 == 0) ? 2 : 1;
 }
 
 int pick_conv_tile(const KArgs& g, int ks_hint = 1, int wk = 1) {
