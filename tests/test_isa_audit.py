@@ -2,7 +2,8 @@
 
 Several GEMM kernels issue register-destination loads from inline asm so that hipcc does not track them (a tracked load
 makes it drain vmcnt to 0 where the value is first used, which would stall the LDS-DMA pipeline): the bias pair of
-gemm_px_kernel, the residual pieces of gemm_x3r_kernel, the residual rows of gemm_fp8p_kernel<RESID_F32>.  Their
+gemm_px_kernel, the residual pieces of gemm_x3r_kernel, the residual rows of gemm_fp8p_kernel<RESID_F32>; conv3x3_c64_kernel
+issues its LDS fragment reads the same way (counted lgkmcnt).  Their
 correctness rests on NO instruction touching a destination register before the hand-counted `s_waitcnt vmcnt` that covers
 the load -- which the source enforces by naming the registers as read-write operands of that wait statement, and which this
 test checks on the code the compiler actually emitted (tools/isa_async_reg_check.py: every path from each load, around
@@ -31,14 +32,16 @@ def gemm_isa(tmp_path_factory):
     return open(out).read()
 
 
-@pytest.mark.parametrize("kernel,min_loads", [
-    ("gemm_px_kernelI4TF16Li0ELb1E", 2), ("gemm_px_kernelI4TF16Li1ELb1E", 2), ("gemm_px_kernelI5TBf16Li0ELb1E", 2), ("gemm_px_kernelI5TBf16Li1ELb1E", 2),
-    ("gemm_px_kernelI4TF16Li0ELb0E", 2), ("gemm_px_kernelI4TF16Li1ELb0E", 2),
-    ("gemm_x3r_kernelI4TF16E", 32), ("gemm_x3r_kernelI5TBf16E", 32),
-    ("gemm_fp8p_kernelILi2E", 16),
+@pytest.mark.parametrize("kernel,min_loads,kind", [
+    ("gemm_px_kernelI4TF16Li0ELb1E", 2, "vm"), ("gemm_px_kernelI4TF16Li1ELb1E", 2, "vm"), ("gemm_px_kernelI5TBf16Li0ELb1E", 2, "vm"),
+    ("gemm_px_kernelI5TBf16Li1ELb1E", 2, "vm"), ("gemm_px_kernelI4TF16Li0ELb0E", 2, "vm"), ("gemm_px_kernelI4TF16Li1ELb0E", 2, "vm"),
+    ("gemm_x3r_kernelI4TF16E", 32, "vm"), ("gemm_x3r_kernelI5TBf16E", 32, "vm"),
+    ("gemm_fp8p_kernelILi2E", 16, "vm"),
+    # conv3x3_c64_kernel: the 72 fragment reads of a tile are issued from asm (ds_read_b128) and released by counted lgkmcnt waits
+    ("conv3x3_c64_kernelI4TF16Li1E", 72, "lds"), ("conv3x3_c64_kernelI5TBf16Li1E", 72, "lds"),
 ])
-def test_asm_loaded_registers_are_fenced(gemm_isa, kernel, min_loads):
-    ok, report, n = audit(gemm_isa, kernel)
+def test_asm_loaded_registers_are_fenced(gemm_isa, kernel, min_loads, kind):
+    ok, report, n = audit(gemm_isa, kernel, kind)
     assert n >= min_loads, f"{kernel}: expected at least {min_loads} asm-issued register loads, found {n}\n{report}"
     assert ok, report
 

@@ -5,6 +5,8 @@ around every backward branch met on the way -- and report the first instruction 
 registers together with the hand-written `s_waitcnt vmcnt` statements passed on that path.  A destination touched with no
 hand-written wait in between (a copy, a spill, an early use) would read stale data; the compiler's own waits do not count,
 it does not know about these loads.  LDS-DMA copies (global_load_lds_*) have no VGPR destination and are skipped.
+kind="lds": the same audit for LDS reads issued from inline asm (ds_read_b*) and released by hand-counted `s_waitcnt lgkmcnt`
+(conv3x3_c64_kernel's fragment ring).
 
 Usage: python tools/isa_async_reg_check.py file.s <mangled-name-substring>      (exit code 1 on a finding)
        from tools.isa_async_reg_check import audit; ok, report, n_loads = audit(text, key)
@@ -14,6 +16,7 @@ import sys
 
 _REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)\b")
 _LOAD = re.compile(r"global_load_dword(x2|x3|x4)?\s")
+_LDS_LOAD = re.compile(r"ds_read_b(32|64|96|128)\s")      # kind="lds": asm-issued LDS reads, released by hand-counted lgkmcnt waits
 
 
 def _regs(text):
@@ -31,7 +34,8 @@ def _dst(line):
     return _regs(m.group(0)) if m else set()
 
 
-def audit(text, key):
+def audit(text, key, kind="vm"):
+    load_re, counter = (_LOAD, "vmcnt") if kind == "vm" else (_LDS_LOAD, "lgkmcnt")
     m = re.search(r"^(_Z\S*" + re.escape(key) + r"\S*):.*?\n(.*?)\n\s*s_endpgm", text, re.S | re.M)
     if not m:
         raise KeyError(f"no kernel matching {key!r}")
@@ -54,7 +58,7 @@ def audit(text, key):
         lines.append((s.split(";")[0].strip(), in_asm))
     report, ok, n_loads = [name], True, 0
     for k, (s, a) in enumerate(lines):
-        if not (a and _LOAD.match(s)):
+        if not (a and load_re.match(s)):
             continue
         n_loads += 1
         dst = _dst(s)
@@ -65,12 +69,12 @@ def audit(text, key):
             end = stop if stop is not None else len(lines)
             while i < end:
                 s2, a2 = lines[i]
-                if a2 and s2.startswith("s_waitcnt") and "vmcnt" in s2:
+                if a2 and s2.startswith("s_waitcnt") and counter in s2:
                     # a wait that names the registers as operands is itself the fence; it touches nothing
-                    waits = waits + (re.search(r"vmcnt\(\d+\)", s2).group(0),)
+                    waits = waits + (re.search(counter + r"\(\d+\)", s2).group(0),)
                     i += 1
                     continue
-                if a2 and _LOAD.match(s2):
+                if a2 and load_re.match(s2):
                     if _dst(s2) & dst:
                         verdicts.append((bool(waits), f"overwritten by another asm load: {s2[:50]}", waits))
                         break
@@ -93,7 +97,7 @@ def audit(text, key):
 
 
 if __name__ == "__main__":
-    good, rep, n = audit(open(sys.argv[1]).read(), sys.argv[2])
+    good, rep, n = audit(open(sys.argv[1]).read(), sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "vm")
     print(rep)
     print(f"{n} asm-issued register loads audited")
     sys.exit(0 if good else 1)
