@@ -183,6 +183,16 @@ class hamer_inference():
         for key in batch:
             if isinstance(batch[key], torch.Tensor):
                 batch[key] = batch[key].to(self.device).float()
+        # the intrinsics go up BEFORE the forward is queued: a pageable host -> device copy waits for everything already on the
+        # stream, and behind `self.model(batch)` that is the whole HaMeR forward -- 19 ms per chunk during which the driver could
+        # not start the next chunk (d_infer flow: 1960 -> hands/s see DESIGN.md); a numpy K is uploaded once and kept
+        if isinstance(k_real, np.ndarray):
+            kb = k_real.tobytes()
+            if getattr(self, "_k_dev", (None, None))[0] != kb:
+                self._k_dev = (kb, torch.from_numpy(np.ascontiguousarray(k_real)).float().to(self.device))
+            k_real = self._k_dev[1]
+        elif isinstance(k_real, torch.Tensor):
+            k_real = k_real.float().to(self.device)
         out, params = self.model(batch)
 
         pred_cam = out['pred_cam']
@@ -196,10 +206,6 @@ class hamer_inference():
         pred_cam_corrected[:, 1] = pred_cam_corrected[:, 1] * flip_correction
 
         if k_real is not None:
-            if isinstance(k_real, np.ndarray):
-                k_real = torch.from_numpy(k_real).float().to(self.device)
-            elif isinstance(k_real, torch.Tensor):
-                k_real = k_real.float().to(self.device)
             if k_real.dim() == 2:
                 fx, fy, cx, cy = k_real[0, 0], k_real[1, 1], k_real[0, 2], k_real[1, 2]
             else:

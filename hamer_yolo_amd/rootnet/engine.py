@@ -79,10 +79,10 @@ class RootNetEngine:
 
     def forward(self, img: torch.Tensor, k_value: torch.Tensor) -> torch.Tensor:
         """depth (B,) = (GAP(features) . w + b) * k_value (ResRootNet.forward_coord, Model_RGB.py:282-292)."""
+        kv = k_value.to(self.device, torch.float32).contiguous()      # (a pageable upload waits for the stream: before the backbone is queued)
         f = self.features(img)
         B, h, w, c = f.shape
         depth = torch.empty(B, device=self.device, dtype=torch.float32)
-        kv = k_value.to(self.device, torch.float32).contiguous()
         L.check(self.lib.hm_gap_linear(L.ptr(f), h * w, c, L.ptr(self.depth_w), self.depth_b, L.ptr(kv), L.ptr(depth), B, self.dt,
                                        L.current_stream()), "hm_gap_linear")
         return depth

@@ -1,4 +1,4 @@
-"""cProfile of one pass of the folder driver (infer.process_batch_manopara) over 64 seeded 1080p .bmp frames: where the HOST time goes."""
+"""cProfile of one pass of the folder driver (infer.process_batch_manopara; DEPTH=1: d_infer.process_batch_manopara with RootNet) over 64 seeded 1080p .bmp frames: where the HOST time goes."""
 import cProfile, io, os, pstats, shutil, sys, tempfile, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -23,12 +23,20 @@ try:
         Image.fromarray(synth.frame_u8(1080, 1920, seed=i % 8).numpy()[:, :, ::-1]).save(os.path.join(ind, f"f{i:04d}.bmp"))
     hi, det = infer.hamer_inference(HCfg), Detector(YCfg)
     import contextlib
+    import numpy as np
+    if os.environ.get("DEPTH") == "1":                  # the d_infer flow: + RootNet root depth per hand
+        from hamer_yolo_amd import d_infer
+        from hamer_yolo_amd.rootnet.Model_RGB import get_model
+        sar, k_real = get_model(), np.array([[1400.0, 0, 960], [0, 1400.0, 540], [0, 0, 1]], np.float32)
+        run = lambda: d_infer.process_batch_manopara(ind, outd, k_real, hamer=hi, detector=det, sar=sar)
+    else:
+        run = lambda: infer.process_batch_manopara(ind, outd, None, hamer=hi, detector=det)
     with contextlib.redirect_stdout(io.StringIO()):
-        infer.process_batch_manopara(ind, outd, None, hamer=hi, detector=det)
+        run(); run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pr = cProfile.Profile(); pr.enable()
-        infer.process_batch_manopara(ind, outd, None, hamer=hi, detector=det)
+        run()
         torch.cuda.synchronize()
         pr.disable()
     print("pass: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
