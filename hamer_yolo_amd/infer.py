@@ -240,10 +240,11 @@ class hamer_inference():
 
 
 # ---------------------------------------------------------------------------------------- batch drivers
-def _read_bmp24(path: str) -> Optional[np.ndarray]:
+def _read_bmp24(path: str, alloc=None) -> Optional[np.ndarray]:
     """Uncompressed 24-bit BMP (what frame dumps usually are) straight into an HxWx3 BGR array: the file already holds BGR rows
     (bottom-up, padded to 4 bytes), so this is one strided copy instead of PIL's decode + RGB conversion + channel reversal
-    (3 ms instead of 35 ms per 1080p frame on the build host).  None for anything else."""
+    (3 ms instead of 35 ms per 1080p frame on the build host).  None for anything else.  ``alloc(shape)`` may supply the
+    destination array (the folder drivers hand out page-locked slots, so the strided copy IS the staging copy)."""
     import struct
     with open(path, "rb") as f:
         head = f.read(54)
@@ -259,14 +260,18 @@ def _read_bmp24(path: str) -> Optional[np.ndarray]:
     if len(buf) < stride * abs(h):
         return None
     rows = np.frombuffer(buf, dtype=np.uint8).reshape(abs(h), stride)[:, :w * 3].reshape(abs(h), w, 3)
-    return np.ascontiguousarray(rows[::-1] if h > 0 else rows)
+    dst = alloc((abs(h), w, 3)) if alloc is not None else None
+    if dst is None:
+        return np.ascontiguousarray(rows[::-1] if h > 0 else rows)
+    np.copyto(dst, rows[::-1] if h > 0 else rows)
+    return dst
 
 
-def _imread_bgr(path: str) -> Optional[np.ndarray]:
+def _imread_bgr(path: str, alloc=None) -> Optional[np.ndarray]:
     """cv2.imread stand-in (infer.py:1252): HxWx3 uint8 BGR, None when unreadable."""
     try:
         if path.lower().endswith(".bmp"):
-            im = _read_bmp24(path)
+            im = _read_bmp24(path, alloc)
             if im is not None:
                 return im
         from PIL import Image
@@ -344,6 +349,33 @@ def _driver_streams(dev, n: int):
     return get_streams(dev, n)
 
 
+class _PinnedFrames:
+    """Page-locked frame slots of one shape for the folder drivers' decoders: file i of a pass decodes into slot i % n, and the
+    upload of a chunk is one asynchronous host -> device copy per frame straight from the slots -- no staging copy (it was 5 ms
+    of a 100 ms pass of 64 frames, with nothing to overlap at the start of a pass).  n covers the decode-ahead window plus three
+    chunks, so a slot is rewritten only after the chunk that used it has been finished (its stream synchronised)."""
+    _cache: Dict = {}
+    _lock = None
+
+    def __init__(self, shape, n):
+        self.shape, self.n = tuple(shape), n
+        self.buf = torch.empty((n,) + self.shape, dtype=torch.uint8, pin_memory=True)
+        self.views = self.buf.numpy()
+
+    @classmethod
+    def get(cls, shape, n):
+        import threading
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        with cls._lock:
+            ring = cls._cache.get(tuple(shape))
+            if ring is None or ring.n < n:
+                if len(cls._cache) >= 2:                       # (folders of many frame sizes: do not hoard page-locked memory)
+                    cls._cache.clear()
+                ring = cls._cache[tuple(shape)] = cls(shape, n)
+            return ring
+
+
 def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_step: int = FRAMES_PER_STEP, in_flight: int = 2,
                         decode_threads: Optional[int] = None, depth_model=None):
     """Yields ``(path, detection_list, hands)`` per image that has detections, in path order; ``hands`` is a dict of host
@@ -371,12 +403,19 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             yield cur
 
     pinned = {}                       # (stream slot, frame shape) -> page-locked staging buffer of one chunk of frames
+    slot_of = {}                      # id(decoded array) -> its page-locked slot (tensor), for the frames of the current step
 
     def upload(chunk, slot, pool):
         """The chunk's frames -> device through a page-locked staging buffer: the copies into it run on the decode pool's
         threads, the transfer itself is one asynchronous H2D on the chunk's stream (a pageable `.to(device)` per frame
         costs the host 1-1.5 ms each, in series with everything else it has to do)."""
         shape = chunk[0][1].shape
+        srcs = [slot_of.get(id(im)) for _, im in chunk]
+        if all(t is not None for t in srcs):               # decoded into page-locked slots: one asynchronous copy per frame
+            d = torch.empty((len(chunk),) + tuple(shape), dtype=torch.uint8, device=dev)
+            for i, t in enumerate(srcs):
+                d[i].copy_(t, non_blocking=True)
+            return [d[i] for i in range(len(chunk))]
         key = (slot, shape)
         if key not in pinned:
             pinned[key] = torch.empty((frames_per_step,) + tuple(shape), dtype=torch.uint8, pin_memory=True)
@@ -438,10 +477,23 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
         ahead = frames_per_step * 4
         futs, submitted = deque(), 0
 
+        n_slots = min(len(image_paths), ahead + 3 * frames_per_step)
+
+        def decode(index, path):
+            """One file -> (HxWx3 BGR array, its page-locked slot as a tensor or None)."""
+            taken = []
+
+            def alloc(shape):
+                ring = _PinnedFrames.get(shape, n_slots)
+                taken.append(ring.buf[index % ring.n])
+                return ring.views[index % ring.n]
+            im = _imread_bgr(path, alloc if dev.type == "cuda" else None)
+            return im, (taken[0] if taken and im is not None else None)
+
         def top_up(upto):
             nonlocal submitted
             while submitted < min(len(image_paths), upto):
-                futs.append(pool.submit(_imread_bgr, image_paths[submitted]))
+                futs.append(pool.submit(decode, submitted, image_paths[submitted]))
                 submitted += 1
 
         top_up(ahead)
@@ -449,7 +501,10 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
         k = 0
         for st in range(0, len(image_paths), frames_per_step):
             paths = image_paths[st:st + frames_per_step]
-            images = [futs.popleft().result() for _ in paths]
+            decoded = [futs.popleft().result() for _ in paths]
+            images = [d[0] for d in decoded]
+            slot_of.clear()
+            slot_of.update({id(im): t for im, t in decoded if im is not None and t is not None})
             top_up(st + len(paths) + ahead)
             for chunk in chunks_of(paths, images):
                 try:
