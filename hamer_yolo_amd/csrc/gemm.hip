@@ -2408,6 +2408,194 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const KArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3, STRIDE 2, 32 -> 64 channels (round 3): the layer behind the stem (384 x 640 -> 192 x 320), 252 MB in and 126 MB out for
+// 36 GFLOP -- as an implicit GEMM 122 us for 16 frames, 2.6x its HBM time.  The scheme of conv3x3_c64_kernel with two changes:
+//   * the 17 x 33 pixel halo of an 8 x 16 output tile is staged as TWO planes, even and odd input columns, so that the 16 pixels of
+//     a fragment (input columns 2 x + kx) are consecutive 64-byte rows of one plane (kx = 0: even plane, 1: odd plane, 2: even
+//     plane, one entry on);
+//   * 64-byte rows (32 channels = one 32-deep MFMA step per tap) put four rows in a 256-byte bank row, and the swizzle that keeps
+//     ds_read_b128's four non-contiguous 16-lane groups conflict-free is: 16-byte chunk c of row e sits at c ^ 2 ((e >> 2) & 1)
+//     (found by exhaustive search over chunk permutations keyed on e; the GEMM's c ^ (e & 7) does not apply to 4-chunk rows).
+//     (e >> 2) & 1 of a fragment's row is ((lane + m) >> 2) & 1 with m a compile-time constant of (tap, pixel row): again eight
+//     precomputed lane addresses and an immediate offset serve every read.
+// Weights (this wave's 32 channels x 288) stay in registers (18 fragments), nine steps of 4 reads + 8 MFMAs per tile.  K order and
+// epilogue arithmetic are the implicit GEMM's (its K-step of 64 is two taps, each one 32-deep MFMA): bit-identical to it.
+template <class T, int ACT>
+__global__ __launch_bounds__(256, 2) void conv3x3_s2c32_kernel(const KArgs g) {
+  using elem = typename T::elem;
+  using vec8 = typename T::vec8;
+  constexpr int TH = 8, TW = 16, HH = 2 * TH + 1, HWD = 2 * TW + 1;        // halo 17 x 33 input pixels
+  constexpr int PITCH = 17, PLANE = 296;                                   // entries per halo row of a plane; entries per plane (17 x 17 = 289 -> 296)
+  constexpr int ENTRIES = 2 * PLANE, PIECES = ENTRIES / 16, HBUF = PIECES * 1024, NJ = (PIECES + 3) / 4;   // 592 rows of 64 B = 37 pieces
+  static_assert(ENTRIES % 16 == 0 && PLANE % 8 == 0, "whole 1-KB pieces; plane offsets keep the swizzle phase");
+  extern __shared__ __attribute__((aligned(16))) char smem[];                 // 2 x HBUF | bias [64] f32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g4 = lane >> 4, pg = wave >> 1, chh = wave & 1;
+  const elem* X = (const elem*)g.X;
+  vec8 wf[9][2];                                       // fragment (tap, ni): rows 32 chh + 16 ni + li, K = 32 tap + 8 g4 .. +7
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      wf[tap][ni] = *(const vec8*)((const elem*)g.W + (size_t)(32 * chh + 16 * ni + li) * g.ldw + 32 * tap + 8 * g4);
+  if (tid < 64) ((float*)(smem + 2 * HBUF))[tid] = g.bias[tid];
+
+  const int tiles_x = (g.Wout + TW - 1) / TW, tiles_y = (g.Hout + TH - 1) / TH, tpi = tiles_x * tiles_y;
+  const int ntiles = (g.M / (g.Hout * g.Wout)) * tpi;
+  // copy j of this wave = piece 4 j + wave = rows 16 (4 j + wave) + (lane >> 2), physical chunk lane & 3
+  const int srow = lane >> 2;
+  auto entry_geom = [&](int e, int& hy, int& hx, bool& real) {
+    const int pl = e >= PLANE ? 1 : 0, r = e - pl * PLANE;
+    hy = r / PITCH;
+    const int idx = r - hy * PITCH;
+    hx = 2 * idx + pl;
+    real = r < HH * PITCH && hx < HWD;
+  };
+  unsigned voff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int e = 16 * (4 * j + wave) + srow, c = (lane & 3) ^ (((e >> 2) & 1) << 1);
+    int hy, hx; bool real;
+    entry_geom(e, hy, hx, real);
+    voff[j] = (real && e < ENTRIES) ? (unsigned)(((hy * g.Wd + hx) * g.ldx + c * 8) * 2) : 0u;
+  }
+  auto issue_halo = [&](int tile, int buf) {
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int y0 = 2 * ty * TH - 1, x0 = 2 * tx * TW - 1;
+    char* dst = smem + buf * HBUF;
+    if (y0 >= 0 && x0 >= 0 && y0 + HH <= g.H && x0 + HWD <= g.Wd) {          // the whole halo lies inside the map (uniform)
+      const char* base = (const char*)(X + (((size_t)n * g.H + y0) * g.Wd + x0) * g.ldx);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (4 * j + wave < PIECES) glds16_hidden_s(base, voff[j], dst + (4 * j + wave) * 1024);
+    } else {
+      const elem* img = X + (size_t)n * g.H * g.Wd * g.ldx;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (4 * j + wave < PIECES) {
+          const int e = 16 * (4 * j + wave) + srow, c = (lane & 3) ^ (((e >> 2) & 1) << 1);
+          int hy, hx; bool real;
+          entry_geom(e, hy, hx, real);
+          const int iy = y0 + hy, ix = x0 + hx;
+          const bool ok = real && iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
+          const elem* src = ok ? img + ((size_t)iy * g.Wd + ix) * g.ldx + c * 8 : (const elem*)g.zeros;
+          glds16_hidden_v(src, dst + (4 * j + wave) * 1024);
+        }
+    }
+  };
+  // fragment of (tap, pixel row mi): plane kx & 1, rows (2 (4 pg + mi) + ky) * 17 + (kx == 2) + li, chunk g4 ^ 2 ((row >> 2) & 1);
+  // (row >> 2) & 1 = ((li + m) >> 2) & 1 with m = ((2 mi + ky) * 17 + (kx == 2)) & 7 (8 pg * 17 and the plane offset are 0 mod 8)
+  unsigned faddr[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    faddr[m] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
+               (unsigned)((8 * pg * PITCH + li) * 64 + ((g4 ^ ((((li + m) >> 2) & 1) << 1)) << 4));
+  const unsigned yoff = (unsigned)((li * g.ldc + (g4 & 1) * 16 + (g4 >> 1) * 8) * 2);
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;
+  bool whole = false;
+  if (tile < ntiles) issue_halo(tile, 0);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(wf[tap][ni]));      // the weight loads complete here (see conv3x3_c64_kernel)
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    if (whole) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + (int)gridDim.x < ntiles) issue_halo(tile + gridDim.x, buf ^ 1);
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    vec8 xr[3][4];
+    auto rd = [&](auto sc) {
+      constexpr int tap = decltype(sc)::value, r = tap % 3, ky = tap / 3, kx = tap % 3;
+      vec8 (&x)[4] = xr[r];
+      unsigned (&fa)[8] = faddr;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[0]) : "v"(fa[((0 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (0 + ky) * PITCH + (kx == 2)) * 64));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[1]) : "v"(fa[((2 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (2 + ky) * PITCH + (kx == 2)) * 64));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[2]) : "v"(fa[((4 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (4 + ky) * PITCH + (kx == 2)) * 64));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[3]) : "v"(fa[((6 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (6 + ky) * PITCH + (kx == 2)) * 64));
+    };
+    auto step = [&](auto sc) {
+      constexpr int tap = decltype(sc)::value, r = tap % 3;
+      if constexpr (tap + 2 < 9) rd(std::integral_constant<int, tap + 2>{});
+      vec8 (&x)[4] = xr[r];
+      constexpr int newer = (9 - 1 - tap < 2 ? 9 - 1 - tap : 2) * 4;
+      if constexpr (newer == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+      else if constexpr (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = T::mfma(wf[tap][ni], xr[r][mi], acc[mi][ni]);
+    };
+    rd(std::integral_constant<int, 0>{});
+    rd(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int ox = tx * TW + li;
+    whole = (ty + 1) * TH <= g.Hout && (tx + 1) * TW <= g.Wout;
+    char* ytile = (char*)g.C + ((((size_t)n * g.Hout + ty * TH + 4 * pg) * g.Wout + tx * TW) * g.ldc + 32 * chh) * 2;
+    f32x4_t bv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bv[h] = *(const f32x4_t*)(smem + 2 * HBUF + (32 * chh + 16 * h + 4 * g4) * 4);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int oy = ty * TH + 4 * pg + mi;
+      unsigned pk[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4_t a = acc[mi][h], bb = bv[h];
+        typename T::vec4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = __fadd_rn(a[q], bb[q]);
+          if (ACT == 1) v = silu(v);
+          if (ACT == 2) v = fmaxf(v, 0.f);
+          o[q] = (elem)v;
+        }
+        const u32x2 w = __builtin_bit_cast(u32x2, o);
+        pk[h][0] = w[0]; pk[h][1] = w[1];
+      }
+      const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+      const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+      if (whole || (ox < g.Wout && oy < g.Hout)) {
+        const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        const char* yrow = ytile + (size_t)mi * g.Wout * g.ldc * 2;
+        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");
+      }
+    }
+    {
+      const unsigned d = buf ? (unsigned)-HBUF : (unsigned)HBUF;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) faddr[m] += d;
+    }
+  }
+}
+
+template <class T, int ACT>
+int launch_conv_s2c32(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 2 * 37 * 1024 + 256;
+  auto kern = conv3x3_s2c32_kernel<T, ACT>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_conv2d_nhwc: cannot raise the dynamic LDS limit")) return rc;
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int ntiles = (g.M / (g.Hout * g.Wout)) * ((g.Wout + 15) / 16) * ((g.Hout + 7) / 8);
+  const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, g);
+  return hm_check_launch("hm_conv2d_nhwc (3x3 stride 2, 32 -> 64)");
+}
+
 int conv_c64_tiles(const KArgs& g) { return (g.M / (g.Hout * g.Wout)) * ((g.Wout + 15) / 16) * ((g.Hout + 7) / 8); }
 
 template <class T, int ACT>
@@ -2443,6 +2631,9 @@ int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
   // Measured per layer, 16 frames of 1080p (tools/prof_yolo.py): 3(8) -> 32: 192 -> 93 us (one frame 18 -> 11.5); 32 -> 64 stride 2:
   // 128 -> 134 and 64 -> 64: 143 -> 161 -- with 9 / 18 K-steps of four dependent global loads each and two waves per SIMD the
   // direct form is bound by load latency there (it would need a ring of fragments many K-steps deep): only the first layer takes it.
+  if (cin == 32 && g.N == 64 && g.stride == 2 && g.pad == 1 && hm_option(HM_OPT_CONV_DIRECT) != 2 && (size_t)20 * g.Wd * g.ldx * 2 < (1ull << 31) &&
+      (hm_option(HM_OPT_CONV_DIRECT) == 3 || conv_c64_tiles(g) >= 1024))
+    return launch_conv_s2c32<T, 1>(g, s);
   if (cin == 8 && g.N == 32 && g.stride == 1) return launch_conv_direct<T, 8, 32, 1, 1>(g, s);
   taken = false;
   return HM_OK;
