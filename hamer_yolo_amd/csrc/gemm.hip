@@ -2241,6 +2241,10 @@ __device__ __forceinline__ void glds16_hidden_v(const void* src, void* lds_wave_
                : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
+// asm_store_note: the epilogues of the kernels below issue their 16-byte stores from inline asm (uniform base + lane offset).  A
+// store of more than 64 bits followed by a write of its data registers needs a wait state that hipcc's hazard recogniser inserts
+// for ITS stores but cannot for one it does not see: without the s_nop, a short epilogue (conv1x1_wreg_kernel, K = 128) let the
+// moves that assemble the next store's data overtake the read of the previous one's (lanes 12-15 of a row, first dwords wrong).
 template <class T, int ACT>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const KArgs g) {
   using elem = typename T::elem;
@@ -2397,7 +2401,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const KArgs g) {
       if (whole || (ox < g.Wout && oy < g.Hout)) {      // uniform row base + this lane's tile-invariant 32-bit offset (from asm:
         const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};   // hipcc would add them into a 64-bit register pair per store)
         const char* yrow = ytile + (size_t)mi * g.Wout * g.ldc * 2;
-        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");   // (s_nop: see asm_store_note)
       }
     }
     {                                                  // the fragment addresses follow the halo buffer
@@ -2571,7 +2575,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2c32_kernel(const KArgs g) {
       if (whole || (ox < g.Wout && oy < g.Hout)) {
         const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
         const char* yrow = ytile + (size_t)mi * g.Wout * g.ldc * 2;
-        asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");   // (s_nop: see asm_store_note)
       }
     }
     {
@@ -2596,6 +2600,170 @@ int launch_conv_s2c32(const KArgs& g, hipStream_t s) {
   return hm_check_launch("hm_conv2d_nhwc (3x3 stride 2, 32 -> 64)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions of the large maps with K <= 256 (round 3): 245760 x 256 x 256 and its relatives move 120-250 MB for 8-32 GFLOP
+// and ran at 2.5x their HBM time as implicit GEMMs -- four K-steps between a prologue and an epilogue whose SiLU alone costs
+// more VALU cycles than the K loop costs MFMA cycles.  Same recipe as the 3x3 kernels: a persistent workgroup keeps the WEIGHTS
+// in registers (wave w owns Cout / 4 channels: NI x K/32 fragments), streams 64-pixel tiles of X through a double-buffered LDS
+// image by LDS-DMA with tile-invariant lane offsets, reads fragments through K/32 precomputed lane addresses + immediates (rows
+// are K x 2 = 256 / 512 bytes, a multiple of the 256-byte bank row, so the 16-byte chunk index is XORed with row & 15), one
+// barrier per tile, counted waits, lane-swap epilogue.  K order = the implicit GEMM's: bit-identical.
+template <class T, int K32, int NI, int ACT>
+__global__ __launch_bounds__(256, 2) void conv1x1_wreg_kernel(const KArgs g) {
+  using elem = typename T::elem;
+  using vec8 = typename T::vec8;
+  constexpr int K = K32 * 32, ROWB = K * 2, BM = 64, TILEB = BM * ROWB, PIECES = TILEB / 1024, NJ = PIECES / 4, RPP = 1024 / ROWB;   // rows per piece: 2 / 4
+  constexpr int CPR = ROWB / 16;                       // 16-byte chunks per row: 32 / 16
+  constexpr int NST = 4 * NI / 2;                      // 16-byte stores per wave and tile: 4 pixel tiles x NI / 2 channel pairs
+  static_assert(K32 == 4 || K32 == 8, "K = 128 or 256");
+  extern __shared__ __attribute__((aligned(16))) char smem[];                 // 2 x TILEB | bias [64 NI] f32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g4 = lane >> 4;
+  const int nb = wave * NI * 16;                       // this wave's first output channel
+  vec8 wf[K32][NI];
+#pragma unroll
+  for (int ks = 0; ks < K32; ++ks)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      wf[ks][ni] = *(const vec8*)((const elem*)g.W + (size_t)(nb + 16 * ni + li) * g.ldw + 32 * ks + 8 * g4);
+  for (int c = tid; c < 64 * NI; c += 256) ((float*)(smem + 2 * TILEB))[c] = g.bias[c];
+  // copy j of this wave = piece 4 j + wave = rows RPP (4 j + wave) + lane / CPR, physical chunk lane % CPR = logical chunk ^ (row & 15)
+  unsigned voff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = RPP * (4 * j + wave) + lane / CPR, c = (lane % CPR) ^ (row & 15);
+    voff[j] = (unsigned)((row * g.ldx + c * 8) * 2);
+  }
+  const int ntiles = g.M / BM;                         // (host: M % 64 == 0)
+  auto issue = [&](int tile, int buf) {
+    const char* base = (const char*)((const elem*)g.X + (size_t)tile * BM * g.ldx);
+    char* dst = smem + buf * TILEB;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) glds16_hidden_s(base, voff[j], dst + (4 * j + wave) * 1024);
+  };
+  // fragment (ks, mi): row 16 mi + li, chunk (4 ks + g4) ^ li  ->  one lane address per ks, 16 mi rows as an immediate
+  unsigned faddr[K32];
+#pragma unroll
+  for (int ks = 0; ks < K32; ++ks)
+    faddr[ks] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(li * ROWB + (((4 * ks + g4) ^ li) << 4));
+  const unsigned yoff = (unsigned)((li * g.ldc + (g4 & 1) * 16 + (g4 >> 1) * 8) * 2);
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;
+  if (tile < ntiles) issue(tile, 0);
+#pragma unroll
+  for (int ks = 0; ks < K32; ++ks)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(wf[ks][ni]));      // the weight loads complete here (see conv3x3_c64_kernel)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... and the first tile's rows, so that the loop's wait is the same every time
+  constexpr int MIT = K32 * NI > 16 ? 2 : 4;           // pixel tiles of 16 per pass over K (two passes of 32 pixels when the weights
+                                                       // fill half the register file: 64 accumulator registers would spill)
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    // this tile's rows (issued a tile ago) have landed; the previous epilogue's NST stores (the newest operations) may stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, buf ^ 1);
+    char* ytile = (char*)g.C + ((size_t)tile * BM * g.ldc + nb) * 2;
+#pragma unroll
+    for (int half = 0; half < 4 / MIT; ++half) {
+      f32x4_t acc[MIT][NI];
+#pragma unroll
+      for (int mi = 0; mi < MIT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      vec8 xr[2][MIT];
+      auto rd = [&](auto sc, auto hc) {
+        constexpr int ks = decltype(sc)::value, r = ks & 1, h0 = decltype(hc)::value * MIT;
+        vec8 (&x)[MIT] = xr[r];
+        const unsigned a = faddr[ks];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[0]) : "v"(a), "n"((h0 + 0) * 16 * ROWB));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[1]) : "v"(a), "n"((h0 + 1) * 16 * ROWB));
+        if constexpr (MIT == 4) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[2]) : "v"(a), "n"((h0 + 2) * 16 * ROWB));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[3]) : "v"(a), "n"((h0 + 3) * 16 * ROWB));
+        }
+      };
+      auto step = [&](auto sc, auto hc) {
+        constexpr int ks = decltype(sc)::value, r = ks & 1;
+        if constexpr (ks + 1 < K32) rd(std::integral_constant<int, ks + 1>{}, hc);
+        vec8 (&x)[MIT] = xr[r];
+        if constexpr (MIT == 4) {
+          if constexpr (ks + 1 < K32) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+        } else {
+          if constexpr (ks + 1 < K32) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x[0]), "+v"(x[1]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MIT; ++mi) acc[mi][ni] = T::mfma(wf[ks][ni], xr[r][mi], acc[mi][ni]);
+      };
+      auto run = [&](auto hc) {
+        rd(std::integral_constant<int, 0>{}, hc);
+        step(std::integral_constant<int, 0>{}, hc); step(std::integral_constant<int, 1>{}, hc);
+        step(std::integral_constant<int, 2>{}, hc); step(std::integral_constant<int, 3>{}, hc);
+        if constexpr (K32 == 8) {
+          step(std::integral_constant<int, 4>{}, hc); step(std::integral_constant<int, 5>{}, hc);
+          step(std::integral_constant<int, 6>{}, hc); step(std::integral_constant<int, 7>{}, hc);
+        }
+      };
+      if (half == 0) run(std::integral_constant<int, 0>{});
+      else run(std::integral_constant<int, 1>{});
+#pragma unroll
+      for (int np = 0; np < NI / 2; ++np) {
+        f32x4_t bv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bv[h] = *(const f32x4_t*)(smem + 2 * TILEB + (nb + 16 * (2 * np + h) + 4 * g4) * 4);
+#pragma unroll
+        for (int mi = 0; mi < MIT; ++mi) {
+          unsigned pk[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4_t a = acc[mi][2 * np + h], bb = bv[h];
+            typename T::vec4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float v = __fadd_rn(a[q], bb[q]);
+              if (ACT == 1) v = silu(v);
+              if (ACT == 2) v = fmaxf(v, 0.f);
+              o[q] = (elem)v;
+            }
+            const u32x2 w = __builtin_bit_cast(u32x2, o);
+            pk[h][0] = w[0]; pk[h][1] = w[1];
+          }
+          const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          const char* yrow = ytile + ((size_t)(half * MIT + mi) * 16 * g.ldc + np * 32) * 2;
+          asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");   // (s_nop: see asm_store_note)
+        }
+      }
+    }
+    {
+      const unsigned d = buf ? (unsigned)-TILEB : (unsigned)TILEB;
+#pragma unroll
+      for (int ks = 0; ks < K32; ++ks) faddr[ks] += d;
+    }
+  }
+}
+
+template <class T, int K32, int NI, int ACT>
+int launch_conv1x1_wreg(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 2 * 64 * K32 * 64 + 64 * NI * 4;
+  auto kern = conv1x1_wreg_kernel<T, K32, NI, ACT>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_conv2d_nhwc: cannot raise the dynamic LDS limit")) return rc;
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int ntiles = g.M / 64;
+  const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, g);
+  return hm_check_launch("hm_conv2d_nhwc (1x1, weights in registers)");
+}
+
 int conv_c64_tiles(const KArgs& g) { return (g.M / (g.Hout * g.Wout)) * ((g.Wout + 15) / 16) * ((g.Hout + 7) / 8); }
 
 template <class T, int ACT>
@@ -2616,9 +2784,25 @@ int launch_conv_c64(const KArgs& g, hipStream_t s) {
 template <class T>
 int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
   taken = false;
-  if (hm_option(HM_OPT_CONV_DIRECT) == 1 || epilogue != HM_EPI_SILU || g.ksz != 3 || g.bias == nullptr || (g.ldc & 7) != 0 ||
-      (((uintptr_t)g.C) & 15) != 0 || g.ldw < ((9 << g.cin_log2) + 31) / 32 * 32)
+  if (hm_option(HM_OPT_CONV_DIRECT) == 1 || epilogue != HM_EPI_SILU || g.bias == nullptr || (g.ldc & 7) != 0 || (((uintptr_t)g.C) & 15) != 0)
     return HM_OK;
+  if (g.ksz == 1 && g.stride == 1 && hm_option(HM_OPT_CONV_DIRECT) != 2) {
+    // 1x1 with K = 128 / 256 and Cout = 128 / 256 (M % 64 == 0, from 200 tiles of 64 pixels): 16 frames: 245760 x 256 x 256 76 -> 60 us,
+    // x 128 x 256 48 -> 37, x 128 x 128 40 -> 30; 61440 rows 25 -> 23; 15360 rows 11.3 -> 8.8; 3840 rows (60 tiles) 9.5 -> 11.4: not
+    // taken.  Bit-identical to the implicit GEMM, so the choice may depend on the batch.
+    const int cin1 = 1 << g.cin_log2;
+    const bool big = hm_option(HM_OPT_CONV_DIRECT) == 3 || g.M / 64 >= 200;
+    if (g.M % 64 == 0 && g.K == cin1 && g.ldw >= g.K && big && (size_t)64 * g.ldx * 2 < (1ull << 31)) {
+      taken = true;
+      if (cin1 == 256 && g.N == 256) return launch_conv1x1_wreg<T, 8, 4, 1>(g, s);
+      if (cin1 == 256 && g.N == 128) return launch_conv1x1_wreg<T, 8, 2, 1>(g, s);
+      if (cin1 == 128 && g.N == 128) return launch_conv1x1_wreg<T, 4, 2, 1>(g, s);
+      if (cin1 == 128 && g.N == 256) return launch_conv1x1_wreg<T, 4, 4, 1>(g, s);
+      taken = false;
+    }
+    return HM_OK;
+  }
+  if (g.ksz != 3 || g.ldw < ((9 << g.cin_log2) + 31) / 32 * 32) return HM_OK;
   const int cin = 1 << g.cin_log2;
   taken = true;
   // 3x3 stride 1, 64 -> 64, when every one of the 512 persistent workgroups gets at least two 8 x 16 tiles (its weight slice is

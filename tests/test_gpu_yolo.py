@@ -210,6 +210,31 @@ def test_conv_3x3_stride2_32_to_64_kernel_equals_the_implicit_gemm(n, H, W, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Co,n,H,W", [(256, 256, 1, 8, 8), (256, 128, 2, 16, 12), (128, 128, 3, 8, 24), (128, 256, 1, 16, 20), (256, 256, 16, 96, 160),
+                                          (128, 128, 16, 96, 160)])
+def test_conv_1x1_weights_in_registers_kernel_equals_the_implicit_gemm(Ci, Co, n, H, W, dt):
+    """Round 3: 1x1 convolutions with K = 128 / 256 and Cout = 128 / 256 on the large maps run on conv1x1_wreg_kernel: the
+    weights in registers for the life of a persistent workgroup, 64-pixel tiles of X streamed through a double-buffered LDS image
+    (chunk index XOR row & 15), K/32 precomputed lane addresses, counted waits, lane-swap epilogue.  Same K order and epilogue as
+    the implicit GEMM: the bytes must be equal to it (HM_OPT_CONV_DIRECT = 1), one tile, several, more tiles than workgroups,
+    input and output as channel slices of wider buffers; and both match torch."""
+    x = synth.uniform("ox", (n, Ci, H, W), 1.0, seed=Ci + W).to(dt).float()
+    w = synth.uniform("ow", (Co, Ci, 1, 1), (3.0 / Ci) ** 0.5, seed=Co).to(dt).float()
+    b = synth.uniform("ob", (Co,), 0.3, seed=3)
+    with L.option(L.HM_OPT_CONV_DIRECT, 3):                                      # 3: at any size (by default from 200 tiles up)
+        direct = _conv_gpu(x, w, b, 1, 1, act=True, dt=dt, ld_extra=64, y_extra=192)
+    if n == 16:
+        assert torch.equal(direct, _conv_gpu(x, w, b, 1, 1, act=True, dt=dt, ld_extra=64, y_extra=192))     # the default takes it here
+    with L.option(L.HM_OPT_CONV_DIRECT, 1):
+        gemm = _conv_gpu(x, w, b, 1, 1, act=True, dt=dt, ld_extra=64, y_extra=192)
+    assert torch.equal(direct, gemm)
+    if n * H * W <= 4096:
+        ref = F.silu(F.conv2d(x.double(), w.double(), b.double())).float()
+        ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        np.testing.assert_allclose(direct.numpy(), ref.numpy(), atol=2e-3, rtol=2 * ulp)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_conv_split_k_exact_and_close(dt):
     """Split-K convolution (hm_conv_args.splitk_ws: few output tiles, long K -- the 12x20 / 24x40 maps of the YOLOv7 neck):
     fp32 partial slabs per K range, added in order by the reduce kernel, then bias + SiLU.  Exact on integer data for 2, 4 and
