@@ -2764,6 +2764,194 @@ int launch_conv1x1_wreg(const KArgs& g, hipStream_t s) {
   return hm_check_launch("hm_conv2d_nhwc (1x1, weights in registers)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3, STRIDE 2, 64 -> 128 channels (the second down-sampling layer, 192 x 320 -> 96 x 160): conv3x3_s2c32_kernel's two planes of
+// input columns with conv3x3_c64_kernel's 128-byte rows (chunk ^ (row & 7), two 32-deep steps per tap), on EIGHT waves = 2 pixel
+// groups x 4 channel groups of 32 (a wave's weight slice is again 36 fragments), one workgroup per CU (two halo buffers of 74 KB).
+// Bit-identical to the implicit GEMM.
+template <class T, int ACT>
+__global__ __launch_bounds__(512, 1) void conv3x3_s2c64_kernel(const KArgs g) {
+  using elem = typename T::elem;
+  using vec8 = typename T::vec8;
+  constexpr int TH = 8, TW = 16, HH = 2 * TH + 1, HWD = 2 * TW + 1;        // halo 17 x 33 input pixels
+  constexpr int PITCH = 17, PLANE = 296, NWV = 8;
+  constexpr int ENTRIES = 2 * PLANE, PIECES = ENTRIES / 8, HBUF = PIECES * 1024, NJ = (PIECES + NWV - 1) / NWV;   // 592 rows of 128 B = 74 pieces
+  extern __shared__ __attribute__((aligned(16))) char smem[];                 // 2 x HBUF | bias [128] f32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g4 = lane >> 4, pg = wave >> 2, chh = wave & 3;
+  const elem* X = (const elem*)g.X;
+  vec8 wf[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        wf[tap][ks][ni] = *(const vec8*)((const elem*)g.W + (size_t)(32 * chh + 16 * ni + li) * g.ldw + 64 * tap + 32 * ks + 8 * g4);
+  if (tid < 128) ((float*)(smem + 2 * HBUF))[tid] = g.bias[tid];
+
+  const int tiles_x = (g.Wout + TW - 1) / TW, tiles_y = (g.Hout + TH - 1) / TH, tpi = tiles_x * tiles_y;
+  const int ntiles = (g.M / (g.Hout * g.Wout)) * tpi;
+  const int srow = lane >> 3;                          // copy j of this wave = piece 8 j + wave = rows 8 (8 j + wave) + srow, physical chunk lane & 7
+  auto entry_geom = [&](int e, int& hy, int& hx, bool& real) {
+    const int pl = e >= PLANE ? 1 : 0, r = e - pl * PLANE;
+    hy = r / PITCH;
+    const int idx = r - hy * PITCH;
+    hx = 2 * idx + pl;
+    real = r < HH * PITCH && hx < HWD;
+  };
+  unsigned voff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int e = 8 * (NWV * j + wave) + srow, c = (lane & 7) ^ (e & 7);
+    int hy, hx; bool real;
+    entry_geom(e, hy, hx, real);
+    voff[j] = (real && e < ENTRIES) ? (unsigned)(((hy * g.Wd + hx) * g.ldx + c * 8) * 2) : 0u;
+  }
+  auto issue_halo = [&](int tile, int buf) {
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int y0 = 2 * ty * TH - 1, x0 = 2 * tx * TW - 1;
+    char* dst = smem + buf * HBUF;
+    if (y0 >= 0 && x0 >= 0 && y0 + HH <= g.H && x0 + HWD <= g.Wd) {
+      const char* base = (const char*)(X + (((size_t)n * g.H + y0) * g.Wd + x0) * g.ldx);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (NWV * j + wave < PIECES) glds16_hidden_s(base, voff[j], dst + (NWV * j + wave) * 1024);
+    } else {
+      const elem* img = X + (size_t)n * g.H * g.Wd * g.ldx;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (NWV * j + wave < PIECES) {
+          const int e = 8 * (NWV * j + wave) + srow, c = (lane & 7) ^ (e & 7);
+          int hy, hx; bool real;
+          entry_geom(e, hy, hx, real);
+          const int iy = y0 + hy, ix = x0 + hx;
+          const bool ok = real && iy >= 0 && iy < g.H && ix >= 0 && ix < g.Wd;
+          const elem* src = ok ? img + ((size_t)iy * g.Wd + ix) * g.ldx + c * 8 : (const elem*)g.zeros;
+          glds16_hidden_v(src, dst + (NWV * j + wave) * 1024);
+        }
+    }
+  };
+  // fragment of (tap, ks, pixel row mi): plane kx & 1, row (2 (4 pg + mi) + ky) * 17 + (kx == 2) + li, chunk (4 ks + g4) ^ (row & 7);
+  // row & 7 = (li + m) & 7 with m = ((2 mi + ky) * 17 + (kx == 2)) & 7, and ks = 1 is key m + 4 (as in conv3x3_c64_kernel)
+  unsigned faddr[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    faddr[m] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
+               (unsigned)((8 * pg * PITCH + li) * 128 + ((g4 ^ ((li + m) & 7)) << 4));
+  const unsigned yoff = (unsigned)((li * g.ldc + (g4 & 1) * 16 + (g4 >> 1) * 8) * 2);
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;
+  bool whole = false;
+  if (tile < ntiles) issue_halo(tile, 0);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(wf[tap][ks][ni]));
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    if (whole) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tile + (int)gridDim.x < ntiles) issue_halo(tile + gridDim.x, buf ^ 1);
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int ox = tx * TW + li;
+    whole = (ty + 1) * TH <= g.Hout && (tx + 1) * TW <= g.Wout;
+    char* ytile = (char*)g.C + ((((size_t)n * g.Hout + ty * TH + 4 * pg) * g.Wout + tx * TW) * g.ldc + 32 * chh) * 2;
+    // two passes over K, two pixel rows each (four rows at once need 32 + 32 more registers than the 144 of the weights leave)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4_t acc[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      vec8 xr[2][2];
+      auto rd = [&](auto sc, auto hc) {
+        constexpr int s = decltype(sc)::value, tap = s >> 1, ks = s & 1, r = s & 1, ky = tap / 3, kx = tap % 3, r0 = 4 * decltype(hc)::value;
+        vec8 (&x)[2] = xr[r];
+        unsigned (&fa)[8] = faddr;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[0]) : "v"(fa[((r0 + 0 + ky) * PITCH + (kx == 2) + 4 * ks) & 7]), "n"(((kx & 1) * PLANE + (r0 + 0 + ky) * PITCH + (kx == 2)) * 128));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[1]) : "v"(fa[((r0 + 2 + ky) * PITCH + (kx == 2) + 4 * ks) & 7]), "n"(((kx & 1) * PLANE + (r0 + 2 + ky) * PITCH + (kx == 2)) * 128));
+      };
+      auto step = [&](auto sc, auto hc) {
+        constexpr int s = decltype(sc)::value, r = s & 1;
+        if constexpr (s + 1 < 18) rd(std::integral_constant<int, s + 1>{}, hc);
+        vec8 (&x)[2] = xr[r];
+        if constexpr (s + 1 < 18) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(x[0]), "+v"(x[1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = T::mfma(wf[s >> 1][s & 1][ni], xr[r][mi], acc[mi][ni]);
+      };
+      auto run = [&](auto hc) {
+        rd(std::integral_constant<int, 0>{}, hc);
+        step(std::integral_constant<int, 0>{}, hc); step(std::integral_constant<int, 1>{}, hc); step(std::integral_constant<int, 2>{}, hc);
+        step(std::integral_constant<int, 3>{}, hc); step(std::integral_constant<int, 4>{}, hc); step(std::integral_constant<int, 5>{}, hc);
+        step(std::integral_constant<int, 6>{}, hc); step(std::integral_constant<int, 7>{}, hc); step(std::integral_constant<int, 8>{}, hc);
+        step(std::integral_constant<int, 9>{}, hc); step(std::integral_constant<int, 10>{}, hc); step(std::integral_constant<int, 11>{}, hc);
+        step(std::integral_constant<int, 12>{}, hc); step(std::integral_constant<int, 13>{}, hc); step(std::integral_constant<int, 14>{}, hc);
+        step(std::integral_constant<int, 15>{}, hc); step(std::integral_constant<int, 16>{}, hc); step(std::integral_constant<int, 17>{}, hc);
+      };
+      if (half == 0) run(std::integral_constant<int, 0>{});
+      else run(std::integral_constant<int, 1>{});
+      f32x4_t bv[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) bv[h] = *(const f32x4_t*)(smem + 2 * HBUF + (32 * chh + 16 * h + 4 * g4) * 4);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int oy = ty * TH + 4 * pg + 2 * half + mi;
+        unsigned pk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4_t a = acc[mi][h], bb = bv[h];
+          typename T::vec4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = __fadd_rn(a[q], bb[q]);
+            if (ACT == 1) v = silu(v);
+            if (ACT == 2) v = fmaxf(v, 0.f);
+            o[q] = (elem)v;
+          }
+          const u32x2 w = __builtin_bit_cast(u32x2, o);
+          pk[h][0] = w[0]; pk[h][1] = w[1];
+        }
+        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        if (whole || (ox < g.Wout && oy < g.Hout)) {
+          const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          const char* yrow = ytile + (size_t)(2 * half + mi) * g.Wout * g.ldc * 2;
+          asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");   // (s_nop: see asm_store_note)
+        }
+      }
+    }
+    {
+      const unsigned d = buf ? (unsigned)-HBUF : (unsigned)HBUF;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) faddr[m] += d;
+    }
+  }
+}
+
+template <class T, int ACT>
+int launch_conv_s2c64(const KArgs& g, hipStream_t s) {
+  constexpr int LDS = 2 * 74 * 1024 + 512;
+  auto kern = conv3x3_s2c64_kernel<T, ACT>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_conv2d_nhwc: cannot raise the dynamic LDS limit")) return rc;
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int ntiles = (g.M / (g.Hout * g.Wout)) * ((g.Wout + 15) / 16) * ((g.Hout + 7) / 8);
+  const int grid = ntiles < cus ? ntiles : cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);
+  return hm_check_launch("hm_conv2d_nhwc (3x3 stride 2, 64 -> 128)");
+}
+
 int conv_c64_tiles(const KArgs& g) { return (g.M / (g.Hout * g.Wout)) * ((g.Wout + 15) / 16) * ((g.Hout + 7) / 8); }
 
 template <class T, int ACT>
@@ -2815,6 +3003,9 @@ int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
   // Measured per layer, 16 frames of 1080p (tools/prof_yolo.py): 3(8) -> 32: 192 -> 93 us (one frame 18 -> 11.5); 32 -> 64 stride 2:
   // 128 -> 134 and 64 -> 64: 143 -> 161 -- with 9 / 18 K-steps of four dependent global loads each and two waves per SIMD the
   // direct form is bound by load latency there (it would need a ring of fragments many K-steps deep): only the first layer takes it.
+  if (cin == 64 && g.N == 128 && g.stride == 2 && g.pad == 1 && hm_option(HM_OPT_CONV_DIRECT) != 2 && (size_t)20 * g.Wd * g.ldx * 2 < (1ull << 31) &&
+      (hm_option(HM_OPT_CONV_DIRECT) == 3 || conv_c64_tiles(g) >= 1024))
+    return launch_conv_s2c64<T, 1>(g, s);
   if (cin == 32 && g.N == 64 && g.stride == 2 && g.pad == 1 && hm_option(HM_OPT_CONV_DIRECT) != 2 && (size_t)20 * g.Wd * g.ldx * 2 < (1ull << 31) &&
       (hm_option(HM_OPT_CONV_DIRECT) == 3 || conv_c64_tiles(g) >= 1024))
     return launch_conv_s2c32<T, 1>(g, s);

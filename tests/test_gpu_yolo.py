@@ -186,16 +186,18 @@ def test_conv_3x3_64_to_64_kernel_equals_the_implicit_gemm(n, H, W, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Co", [(32, 64), (64, 128)])
 @pytest.mark.parametrize("n,H,W", [(2, 16, 32), (1, 48, 96), (3, 37, 75), (2, 10, 140), (1, 80, 32), (2, 33, 34), (16, 192, 320)])
-def test_conv_3x3_stride2_32_to_64_kernel_equals_the_implicit_gemm(n, H, W, dt):
+def test_conv_3x3_stride2_32_to_64_kernel_equals_the_implicit_gemm(n, H, W, Ci, Co, dt):
     """Round 3: the 3x3 stride-2 32 -> 64 layer behind the stem runs on conv3x3_s2c32_kernel: weights in registers, the 17 x 33
     input halo of an 8 x 16 output tile staged once per tile as two planes (even / odd input columns) of 64-byte rows with the
     chunk swizzle c ^ 2 ((row >> 2) & 1), one barrier per tile, counted waits.  Same K order and epilogue arithmetic as the
     implicit GEMM: the bytes must be equal to it (HM_OPT_CONV_DIRECT = 1) on even and odd input sizes, maps smaller than a tile,
-    tiles overhanging on either side, more tiles than workgroups, channel slices of wider buffers; and both match torch."""
-    x = synth.uniform("sx", (n, 32, H, W), 1.0, seed=H + W).to(dt).float()
-    w = synth.uniform("sw", (64, 32, 3, 3), (3.0 / (32 * 9)) ** 0.5, seed=7).to(dt).float()
-    b = synth.uniform("sb", (64,), 0.3, seed=3)
+    tiles overhanging on either side, more tiles than workgroups, channel slices of wider buffers; and both match torch.
+    (64, 128): conv3x3_s2c64_kernel, the same planes with 128-byte rows on eight waves, two passes of two pixel rows."""
+    x = synth.uniform("sx", (n, Ci, H, W), 1.0, seed=H + W).to(dt).float()
+    w = synth.uniform("sw", (Co, Ci, 3, 3), (3.0 / (Ci * 9)) ** 0.5, seed=7).to(dt).float()
+    b = synth.uniform("sb", (Co,), 0.3, seed=3)
     with L.option(L.HM_OPT_CONV_DIRECT, 3):                                      # 3: at any size (by default from 1024 tiles up)
         direct = _conv_gpu(x, w, b, 3, 2, act=True, dt=dt, ld_extra=32, y_extra=192)
     if n == 16:

@@ -40,6 +40,7 @@ def gemm_isa(tmp_path_factory):
     # conv3x3_c64_kernel: the 72 fragment reads of a tile are issued from asm (ds_read_b128) and released by counted lgkmcnt waits
     ("conv3x3_c64_kernelI4TF16Li1E", 72, "lds"), ("conv3x3_c64_kernelI5TBf16Li1E", 72, "lds"),
     ("conv3x3_s2c32_kernelI4TF16Li1E", 36, "lds"), ("conv3x3_s2c32_kernelI5TBf16Li1E", 36, "lds"),
+    ("conv3x3_s2c64_kernelI4TF16Li1E", 72, "lds"),
     ("conv1x1_wreg_kernelI4TF16Li8ELi4ELi1E", 32, "lds"), ("conv1x1_wreg_kernelI4TF16Li4ELi2ELi1E", 16, "lds"), ("conv1x1_wreg_kernelI5TBf16Li8ELi2ELi1E", 16, "lds"),
 ])
 def test_asm_loaded_registers_are_fenced(gemm_isa, kernel, min_loads, kind):
