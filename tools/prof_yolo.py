@@ -19,7 +19,8 @@ L.check(L.load().hm_set_option(L.HM_OPT_CONV_TILE, int(os.environ.get("CONV_TILE
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_SPLITK, int(os.environ.get("CONV_SPLITK", 0))))   # 1: never split
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_KGROUPS, int(os.environ.get("CONV_KGROUPS", 0))))   # 1: no K groups inside a workgroup
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_DIRECT, int(os.environ.get("CONV_DIRECT", 0))))   # 1: implicit GEMM everywhere, 2: direct stem only
-frames = [synth.frame_u8(1080, 1920, seed=i).cuda() for i in range(F)]
+_chunk = torch.stack([synth.frame_u8(1080, 1920, seed=i) for i in range(F)]).cuda()      # as the folder drivers upload a chunk: slices of one
+frames = [_chunk[i] for i in range(F)]                                                    # tensor -> ONE letterbox launch per pass
 for _ in range(3):
     eng.forward(frames)
 torch.cuda.synchronize()
