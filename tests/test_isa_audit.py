@@ -78,3 +78,26 @@ _Z4loopv:
     assert not audit(bad, "bad")[0]
     assert audit(good, "bad")[0]
     assert not audit(loop, "loop")[0]
+
+
+def test_asm_issued_stores_carry_their_wait_states(gemm_isa):
+    """The direct convolution kernels issue their 16-byte output stores from inline asm (uniform SGPR base + lane offset).  Two
+    hazards hipcc's recogniser cannot handle for an instruction it does not see: (1) a store of more than 64 bits followed by a
+    write of its data registers needs wait states -- every such store must be followed by `s_nop 1` inside the same asm
+    statement (without it conv1x1_wreg_kernel wrote wrong first dwords in lanes 12-15); (2) a VALU write of an SGPR (v_readfirstlane)
+    must not sit within 5 instructions in front of a memory instruction that reads it as its base."""
+    import re
+    n = 0
+    for m in re.finditer(r"^(_ZN\w*(conv3x3_c64|conv3x3_s2c32|conv3x3_s2c64|conv1x1_wreg)_kernel\w*):(.*?)\.amdhsa_kernel", gemm_isa, re.S | re.M):
+        lines = [l.strip() for l in m.group(3).splitlines() if l.strip() and not l.strip().startswith((";", "."))]
+        for i, l in enumerate(lines):
+            mm = re.match(r"global_store_dwordx4 v\d+, v\[\d+:\d+\], s\[(\d+):(\d+)\]", l)
+            if not mm:
+                continue
+            n += 1
+            assert lines[i + 1].startswith("s_nop 1"), (m.group(1), l, lines[i + 1])
+            base = {int(mm.group(1)), int(mm.group(2))}
+            for back in lines[max(0, i - 5):i]:
+                d = re.match(r"v_read(?:first)?lane\w* s(\d+)", back)
+                assert not (d and int(d.group(1)) in base), (m.group(1), back, l)
+    assert n >= 40, n
