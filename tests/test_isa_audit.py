@@ -101,3 +101,17 @@ def test_asm_issued_stores_carry_their_wait_states(gemm_isa):
                 d = re.match(r"v_read(?:first)?lane\w* s(\d+)", back)
                 assert not (d and int(d.group(1)) in base), (m.group(1), back, l)
     assert n >= 40, n
+
+
+def test_direct_convolution_kernels_do_not_spill(gemm_isa):
+    """Their hand-counted `s_waitcnt vmcnt(N)` (N = the stores of the previous epilogue) assume that the copies and those stores
+    are the ONLY vector-memory instructions of the tile loop: a register spill (scratch_store / scratch_load count in vmcnt too)
+    would silently break the count.  They sit at 199-250 VGPRs, so this is a compile-time property worth pinning."""
+    import re
+    seen = 0
+    for m in re.finditer(r"^(_ZN\w*(conv3x3_c64|conv3x3_s2c32|conv3x3_s2c64|conv1x1_wreg|conv3x3_direct)_kernel\w*):(.*?)\.amdhsa_kernel", gemm_isa, re.S | re.M):
+        seen += 1
+        assert "scratch_" not in m.group(3), m.group(1)
+        priv = re.search(re.escape(m.group(1)) + r"\.private_seg_size, (\d+)", gemm_isa)
+        assert priv and int(priv.group(1)) == 0, m.group(1)
+    assert seen >= 16, seen
