@@ -8,9 +8,15 @@ dotted names resolve to the modules of ``hamer_yolo_amd`` -- the SAME module obj
 meta-path finder, so a caller of the reference switches by adding ``import hamer_yolo_amd.compat as compat;
 compat.install()`` before its own imports.  Importing this module installs nothing.
 
-The finder defers to the path finder: a name the caller's own ``sys.path`` can serve (its own ``config.py``, its own
-``model/`` package and every submodule found there) keeps resolving to the caller's code; only dotted names nobody else
-can find -- and the submodules of packages that already are this package's -- resolve to the aliases below.
+Who wins when the caller's ``sys.path`` can serve a name too:
+  * ``hamer`` and ``yolo`` ALWAYS resolve to this package.  The documented caller runs the reference's drivers with ``sys.path``
+    pointing into the reference checkout, which has ``hamer/`` and ``yolo/`` at its root: deferring to the path finder there
+    would make ``install()`` a silent no-op and import the CUDA reference instead.  A foreign package of that name on the path
+    is shadowed, with one ``ImportWarning`` naming it.
+  * ``config``: a ``config`` on the path that holds ``hamer_config.py`` / ``yolo_config.py`` is the reference's and is shadowed
+    the same way; any other ``config`` (the caller's own ``config.py``) keeps resolving to the caller's code.
+  * ``model``: the caller's own ``model/`` package and everything found inside it wins; only ``model.rootnet`` (and ``model``
+    itself when nobody has one) fall through to this package.
 """
 from __future__ import annotations
 
@@ -38,11 +44,32 @@ class _AliasLoader(importlib.abc.Loader):
         pass
 
 
-def _others_can_find(fullname, path) -> bool:
+def _path_spec(fullname, path):
     try:
-        return importlib.machinery.PathFinder.find_spec(fullname, path) is not None
+        return importlib.machinery.PathFinder.find_spec(fullname, path)
     except (ImportError, ValueError):
-        return False
+        return None
+
+
+def _is_reference_config(spec) -> bool:
+    """True when a `config` found on the path is the reference checkout's package (it holds hamer_config.py / yolo_config.py)."""
+    import os
+    for loc in (spec.submodule_search_locations or []):
+        if any(os.path.exists(os.path.join(loc, f)) for f in ("hamer_config.py", "yolo_config.py")):
+            return True
+    return False
+
+
+_warned = set()
+
+
+def _shadow_warning(top, spec):
+    import warnings
+    where = getattr(spec, "origin", None) or list(spec.submodule_search_locations or ["?"])[0]
+    if (top, where) not in _warned:
+        _warned.add((top, where))
+        warnings.warn(f"hamer_yolo_amd.compat: {top!r} resolves to hamer_yolo_amd; the one at {where} on sys.path is shadowed",
+                      ImportWarning, stacklevel=3)
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):
@@ -50,11 +77,16 @@ class _AliasFinder(importlib.abc.MetaPathFinder):
         top, _, _rest = fullname.partition(".")
         parent = sys.modules.get(fullname.rpartition(".")[0]) if "." in fullname else None
         ours = parent is not None and getattr(parent, "__name__", "").startswith("hamer_yolo_amd")
-        # the caller's own code wins: a top-level name its sys.path can serve, and any submodule found inside a package that
-        # is the caller's.  (Submodules of a package that IS one of this package's modules must be aliased here, first:
-        # the path finder would otherwise load a second copy of them under the alias name.)
-        if not ours and _others_can_find(fullname, path):
-            return None
+        # (Submodules of a package that IS one of this package's modules must be aliased here, first: the path finder would
+        # otherwise load a second copy of them under the alias name.)
+        if not ours:
+            foreign = _path_spec(fullname, path)
+            if foreign is not None:
+                shadow = top in ("hamer", "yolo") or (top == "config" and fullname == "config" and _is_reference_config(foreign))
+                if not shadow:
+                    return None                               # the caller's own code wins
+                if fullname == top:
+                    _shadow_warning(top, foreign)
         if fullname == "model":                               # namespace parent of model.rootnet, when the caller has no `model` of its own
             spec = importlib.machinery.ModuleSpec("model", None, is_package=True)
             spec.submodule_search_locations = []
@@ -86,7 +118,7 @@ def install() -> None:
         if mod is not None and not getattr(mod, "__name__", "").startswith("hamer_yolo_amd") and top != "model":
             raise ImportError(f"hamer_yolo_amd.compat: the name {top!r} is already imported from {getattr(mod, '__file__', '?')}")
     _finder = _AliasFinder()
-    sys.meta_path.insert(0, _finder)         # first, but it defers to the path finder for everything the caller's sys.path can serve
+    sys.meta_path.insert(0, _finder)         # first; what it leaves to the caller's sys.path is stated in the module docstring
 
 
 def uninstall() -> None:

@@ -1413,6 +1413,30 @@ int px_default_grid(int tiles, int cus) {
   return (tiles + cus - 1) / cus < (tiles + g248 - 1) / g248 ? cus : g248;
 }
 
+// The grid launch_px takes for `tiles` whole tiles on `cus` CUs (exported as hm_gemm_px_grid for the host tests).
+// HM_OPT_PX_GRID (hm_set_option) wins while it is non-zero and is NOT copied into the start-up default: setting the option back
+// to 0 restores the environment's grid (HM_PX_GRID, read once) or the default below.
+// Default: one workgroup per CU on all but ONE CU of every XCD (248 of 256).  Round 3, interleaved whole-model A/B in one
+// process (tools/bench_model_ab.py, profiles/r03_model_ab_px_grid.log): a lone forward takes 18.50 ms with 240 or 248
+// workgroups against 19.84 with 256 -- the same number of tile rounds for qkv / fc1 (720 / 960 tiles), so it is not
+// quantisation: a 256-workgroup persistent kernel needs every CU of the chip at once, and whichever CU is late (the previous
+// kernel's last waves, the dispatcher) delays one workgroup's whole run of tiles.  With two batches in flight the other
+// stream filled that hole already (17.55 ms either way).
+int px_grid_for(int tiles, int cus) {
+  if (g_px_grid == -2) {
+    const char* e = getenv("HM_PX_GRID");                          // tuning runs, read ONCE: start-up default of HM_OPT_PX_GRID
+    g_px_grid = e ? atoi(e) : -1;
+  }
+  const int opt_grid = hm_option(HM_OPT_PX_GRID);
+  const int forced = opt_grid > 0 ? opt_grid : (g_px_grid > 0 ? g_px_grid : 0);
+  int want = forced > 0 ? forced : px_default_grid(tiles, cus);
+  if (want > cus) want = cus;
+  // a multiple of the 8 XCDs, rounded UP when there are fewer tiles than workgroups (a workgroup without a tile returns at once;
+  // rounded down, 180 tiles on 176 workgroups were two rounds: qkv at 16 hands 67 us against 43 for the 128 x 128 tile)
+  return tiles < want ? ((tiles + 7) & ~7) : (want & ~7);
+}
+extern "C" int hm_gemm_px_grid(int tiles, int cus) { return px_grid_for(tiles, cus > 0 ? cus : 256); }
+
 template <class T, int EPI>
 int launch_px(const KArgs& g, hipStream_t s) {
   constexpr int LDS = 5 * 256 * 128;
@@ -1428,22 +1452,7 @@ int launch_px(const KArgs& g, hipStream_t s) {
   const int tiles = (g.M >> 8) * (g.N >> 8);
   int cus = hm_device_cu_count();
   if (cus <= 0) cus = 256;
-  if (g_px_grid == -2) {
-    const char* e = getenv("HM_PX_GRID");                          // tuning runs, read ONCE: start-up default of HM_OPT_PX_GRID
-    g_px_grid = e ? atoi(e) : -1;
-  }
-  if (const int o = hm_option(HM_OPT_PX_GRID)) g_px_grid = o;      // explicit setter (hm_set_option) wins
-  // Default: one workgroup per CU on all but ONE CU of every XCD (248 of 256).  Round 3, interleaved whole-model A/B in one
-  // process (tools/bench_model_ab.py, profiles/r03_model_ab_px_grid.log): a lone forward takes 18.50 ms with 240 or 248
-  // workgroups against 19.84 with 256 -- the same number of tile rounds for qkv / fc1 (720 / 960 tiles), so it is not
-  // quantisation: a 256-workgroup persistent kernel needs every CU of the chip at once, and whichever CU is late (the previous
-  // kernel's last waves, the dispatcher) delays one workgroup's whole run of tiles.  With two batches in flight the other
-  // stream filled that hole already (17.55 ms either way).
-  int want = g_px_grid > 0 ? g_px_grid : px_default_grid(tiles, cus);
-  if (want > cus) want = cus;
-  // a multiple of the 8 XCDs, rounded UP when there are fewer tiles than workgroups (a workgroup without a tile returns at once;
-  // rounded down, 180 tiles on 176 workgroups were two rounds: qkv at 16 hands 67 us against 43 for the 128 x 128 tile)
-  const int grid = tiles < want ? ((tiles + 7) & ~7) : (want & ~7);
+  const int grid = px_grid_for(tiles, cus);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, s, g);
   return hm_check_launch("hm_gemm");
 }

@@ -39,6 +39,7 @@ int hm_option(int key) {
   return (key >= 0 && key < HM_OPT_COUNT) ? g_opts[key].load(std::memory_order_relaxed) : 0;
 }
 extern "C" int hm_get_option(int key) { return hm_option(key); }
+extern "C" int hm_option_count(void) { return HM_OPT_COUNT; }
 extern "C" int hm_set_option(int key, int value) {
   if (key < 0 || key >= HM_OPT_COUNT) return hm_set_error(HM_ERR_ARG, "hm_set_option: unknown key");
   if (value < 0) return hm_set_error(HM_ERR_ARG, "hm_set_option: value must be >= 0");

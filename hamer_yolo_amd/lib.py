@@ -15,10 +15,13 @@ LIB_PATH = os.path.join(HERE, "libhamer_hip.so")
 HM_DTYPE_BF16, HM_DTYPE_F16, HM_OUT_F32 = 0, 1, 2
 HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 3, 4
 HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU, HM_EPI_GELU_MX8 = 5, 6, 7, 8
-HM_VERSION = 302      # include/hamer_hip.h: load() refuses a library built from another header
-(HM_OPT_PX_GRID, HM_OPT_FP8P_GRID, HM_OPT_FP8_ONE_TILE, HM_OPT_FP8P_RESID, HM_OPT_TOME_NO_SPLITK,
- HM_OPT_TOME_SCALAR_ATTENTION, HM_OPT_RESID_IN_EPILOGUE, HM_OPT_CONV_TILE, HM_OPT_CONV_SPLITK, HM_OPT_PX_LDS_EPILOGUE, HM_OPT_CONV_DIRECT,
- HM_OPT_GEMM_TILE_RULE, HM_OPT_CONV_KGROUPS) = range(13)
+HM_VERSION = 400      # include/hamer_hip.h: load() refuses a library built from another header
+# the HM_OPT_* keys of include/hamer_hip.h, in enum order: load() checks the count against the library's hm_option_count(), and
+# tests/test_host_logic.py parses the header's enum and compares names and values with this table
+OPTION_NAMES = ("HM_OPT_PX_GRID", "HM_OPT_FP8P_GRID", "HM_OPT_FP8_ONE_TILE", "HM_OPT_FP8P_RESID", "HM_OPT_TOME_NO_SPLITK",
+                "HM_OPT_TOME_SCALAR_ATTENTION", "HM_OPT_RESID_IN_EPILOGUE", "HM_OPT_CONV_TILE", "HM_OPT_CONV_SPLITK",
+                "HM_OPT_PX_LDS_EPILOGUE", "HM_OPT_CONV_DIRECT", "HM_OPT_GEMM_TILE_RULE", "HM_OPT_CONV_KGROUPS")
+globals().update({_n: _i for _i, _n in enumerate(OPTION_NAMES)})
 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
@@ -27,6 +30,7 @@ EXPORTS = [
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
     "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes", "hm_yolo_decode_batch", "hm_letterbox_batch",
+    "hm_option_count", "hm_gemm_px_grid",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -171,6 +175,8 @@ def load() -> C.CDLL:
     lib.hm_gemm_set_group_m.argtypes = [i]
     lib.hm_set_option.argtypes = [i, i]
     lib.hm_get_option.argtypes = [i]
+    lib.hm_option_count.argtypes = []
+    lib.hm_gemm_px_grid.argtypes = [i, i]
     lib.hm_prof_begin.argtypes = [i]
     lib.hm_prof_collect.argtypes = [C.POINTER(ProfRecord), i]
     lib.hm_prof_end.argtypes = []
@@ -183,6 +189,9 @@ def load() -> C.CDLL:
     if lib.hm_version() != HM_VERSION:
         raise HipLibraryError(f"{LIB_PATH} reports HM_VERSION {lib.hm_version()}, this binding is written for {HM_VERSION}: "
                               "rebuild it (python -m hamer_yolo_amd.build --force)")
+    if lib.hm_option_count() != len(OPTION_NAMES):
+        raise HipLibraryError(f"{LIB_PATH} has {lib.hm_option_count()} HM_OPT_* keys, this binding names {len(OPTION_NAMES)}: "
+                              "include/hamer_hip.h and lib.OPTION_NAMES have drifted apart")
     _lib = lib
     return lib
 

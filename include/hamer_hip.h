@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HM_VERSION 302   /* round 3: hm_set_option, hm_hamer_weights.tome_r, hm_nms_workspace_bytes(n, cap) -- lib.load() checks it */
+#define HM_VERSION 400   /* round 4: hm_option_count, hm_gemm_px_grid (302 = round 3: hm_set_option, hm_hamer_weights.tome_r) -- lib.load() checks it */
 
 enum { HM_DTYPE_BF16 = 0, HM_DTYPE_F16 = 1 };
 
@@ -103,6 +103,11 @@ enum {
 };
 int hm_set_option(int key, int value);
 int hm_get_option(int key);
+/* HM_OPT_COUNT of the library as built: a binding checks its own key table against it (hamer_yolo_amd/lib.py load()). */
+int hm_option_count(void);
+/* Host-side query, no device work: the workgroup count the persistent 16-bit GEMM takes for `tiles` whole 256 x 256 tiles on a
+ * chip of `cus` compute units (0: 256) under the current HM_OPT_PX_GRID -- tests check that the option is not sticky. */
+int hm_gemm_px_grid(int tiles, int cus);
 
 /* The fp8 flavour of hm_gemm for BASELINE configs[4] ("fp8 ViT-H weights on CDNA4 fp8 MFMA"): C = epilogue(X . W^T) on
  * v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 MFMA rate, half the operand bytes).

@@ -50,15 +50,43 @@ def test_options_are_explicit_setters_not_environment_reads(monkeypatch):
     The switches live behind hm_set_option / hm_get_option; only the two start-up tuning defaults are read from the
     environment, once."""
     lib = L.load()
-    for key in range(13):                                 # HM_OPT_COUNT
+    n_opt = lib.hm_option_count()
+    for key in range(n_opt):                              # HM_OPT_COUNT
         assert lib.hm_get_option(key) == 0
-    assert lib.hm_get_option(13) == 0 and lib.hm_set_option(13, 1) != 0
+    assert lib.hm_get_option(n_opt) == 0 and lib.hm_set_option(n_opt, 1) != 0
     assert lib.hm_set_option(99, 1) != 0 and lib.hm_set_option(L.HM_OPT_FP8P_GRID, 12) != 0 and lib.hm_set_option(0, -1) != 0
     with L.option(L.HM_OPT_FP8P_GRID, 40):
         assert lib.hm_get_option(L.HM_OPT_FP8P_GRID) == 40
     assert lib.hm_get_option(L.HM_OPT_FP8P_GRID) == 0
     src = "".join(open(os.path.join(ROOT, "hamer_yolo_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "hamer_yolo_amd", "csrc")))
     assert sorted(set(re.findall(r'getenv\("(\w+)"\)', src))) == ["HM_GEMM_VARIANT", "HM_PX_GRID"]
+
+
+def test_option_table_of_the_binding_is_the_headers_enum():
+    """lib.py names the HM_OPT_* keys itself; the header's enum is the truth.  Names, values and the count must agree
+    (load() also checks the count against the built library)."""
+    hdr = open(os.path.join(ROOT, "include", "hamer_hip.h")).read()
+    keys = re.findall(r"^\s*(HM_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", hdr, flags=re.M)
+    count = int(dict(keys).pop("HM_OPT_COUNT"))
+    named = [(k, int(v)) for k, v in keys if k != "HM_OPT_COUNT"]
+    assert named == [(n, i) for i, n in enumerate(L.OPTION_NAMES)]
+    assert count == len(L.OPTION_NAMES) == L.load().hm_option_count()
+    for i, n in enumerate(L.OPTION_NAMES):
+        assert getattr(L, n) == i
+
+
+def test_persistent_grid_option_is_not_sticky():
+    """HM_OPT_PX_GRID used to be copied into the start-up default on first use, so an A/B arm that set it back to 0
+    kept the previous arm's grid.  hm_gemm_px_grid reports the grid launch_px takes (host arithmetic only)."""
+    lib = L.load()
+    if os.environ.get("HM_PX_GRID"):
+        pytest.skip("HM_PX_GRID is set: the start-up default is not the built-in one")
+    assert lib.hm_gemm_px_grid(720, 256) == 248 and lib.hm_gemm_px_grid(960, 256) == 248      # qkv / fc1 at 64 hands
+    assert lib.hm_gemm_px_grid(1020, 256) == 256                                              # all CUs when that saves a round
+    assert lib.hm_gemm_px_grid(180, 256) == 184                                               # fewer tiles than workgroups: rounded UP to the XCDs
+    with L.option(L.HM_OPT_PX_GRID, 16):
+        assert lib.hm_gemm_px_grid(720, 256) == 16
+    assert lib.hm_get_option(L.HM_OPT_PX_GRID) == 0 and lib.hm_gemm_px_grid(720, 256) == 248
 
 
 def test_abi_rejects_bad_arguments_without_gpu():
@@ -457,6 +485,35 @@ from yolo.detector import Detector
 print("ok")
 """ % (root, td)
         r = subprocess.run([sys.executable, "-c", code2], cwd=td, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+    # ADVICE r3: the documented caller has the REFERENCE checkout on sys.path, whose root holds hamer/, yolo/ and config/
+    # ({hamer,yolo}_config.py inside).  install() must not be a silent no-op there: the aliases win, with a warning.
+    with tempfile.TemporaryDirectory() as td:
+        for pkg, files in (("yolo", {"detector.py": "Detector = 'REFERENCE'\n"}), ("hamer", {"models.py": "load_hamer = 'REFERENCE'\n"}),
+                           ("config", {"yolo_config.py": "yolo_opt = 'REFERENCE'\n", "hamer_config.py": "hamer_opt = 'REFERENCE'\n"})):
+            os.makedirs(os.path.join(td, pkg))
+            open(os.path.join(td, pkg, "__init__.py"), "w").write("")
+            for fn, body in files.items():
+                open(os.path.join(td, pkg, fn), "w").write(body)
+        code3 = r"""
+import sys, warnings
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import hamer_yolo_amd.compat as compat
+compat.install()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    from yolo.detector import Detector
+    from hamer.models import load_hamer
+    from config.yolo_config import yolo_opt
+    from config.hamer_config import hamer_opt
+import hamer_yolo_amd.yolo.detector as D, hamer_yolo_amd.hamer.models as M, hamer_yolo_amd.config.yolo_config as Y
+assert Detector is D.Detector and load_hamer is M.load_hamer and yolo_opt is Y.yolo_opt and hamer_opt != 'REFERENCE'
+shadowed = sorted(str(x.message).split("'")[1] for x in w if issubclass(x.category, ImportWarning) and "shadowed" in str(x.message))
+assert shadowed == ["config", "hamer", "yolo"], shadowed
+print("ok")
+""" % (root, td)
+        r = subprocess.run([sys.executable, "-c", code3], cwd=td, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
 
 
