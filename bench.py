@@ -86,16 +86,47 @@ def cpu_baseline(cfg, sd_dev, mano_cpu, seconds: float = 12.0):
                       f"processes one crop per forward), ViT-H/16 + decoder + MANO, fp32 torch CPU oracle"}
 
 
-def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass: int = 4, long_chunks: int = 0):
+def cpu_baseline_detector(yolo_weights: str, seconds: float = 8.0):
+    """the detector leg of configs[2] on the host cores -- the oracle restatement of Detector.detect
+    (yolo/detector.py:106-153: letterbox, fused YOLOv7 forward in fp32 as the reference's CPU branch :110-112, decode, NMS,
+    scale_coords) on ONE seeded 1080p frame, repeated for a bounded time."""
+    from hamer_yolo_amd.yolo import arch, fuse
+    from hamer_yolo_amd.yolo.detector import attempt_load
+    from oracle import yolo_ref
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    sd, nc, _ = attempt_load(yolo_weights)
+    layers = arch.yolov7_layers()
+    fused = fuse.fuse_state_dict(sd, arch.conv_specs(layers, 3, nc))
+    frame = synth.frame_u8(1080, 1920, seed=0).numpy()
+    with torch.no_grad():
+        yolo_ref.detect(layers, fused, frame, nc, arch.ANCHORS)                 # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            dets = yolo_ref.detect(layers, fused, frame, nc, arch.ANCHORS)[0]
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 8:
+                break
+    return {"value": round(n / dt, 3), "unit": "frames/s", "s_per_frame": round(dt / n, 4), "cores": threads, "kind": "port",
+            "sample": f"{n} passes of one seeded 1080p frame ({dt:.1f} s): letterbox + fused YOLOv7 fp32 + decode + NMS + scale_coords, "
+                      f"torch CPU oracle (oracle/yolo_ref.detect), {len(dets)} boxes"}
+
+
+def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass: int = 4, long_chunks: int = 0, rank: int = 0,
+            world: int = 1, want_roofline: bool = False):
     """BASELINE configs[2], timed through the product driver itself: a folder of seeded 1080p frames on disk ->
-    hamer_yolo_amd.infer.process_batch_manopara (thread-pool decode, chunks of --frames frames: one batched YOLOv7 pass + NMS,
-    all hands of the chunk cropped into one batch, one HaMeR forward, camera step, two chunks in flight) -> one .npy per
-    frame.  The synthetic detector (synth.yolo_state_dict seed 2, obj_bias -2.2, cls_bias 0) finds ~10 boxes per frame;
-    a step = one pass over the folder, value = hands written per second (file decode and .npy writes included)."""
+    hamer_yolo_amd.infer.process_batch_manopara (thread-pool decode into page-locked slots, detector passes of --frames frames at
+    the start and up to 48 afterwards: one batched YOLOv7 pass + NMS each, hands queued across frames and cropped 64 at a time
+    into ONE HaMeR forward, camera step, batches in flight on two streams) -> one .npy per frame.  A step = one pass over the
+    folder, value = hands that went through HaMeR per second (file decode and .npy writes included).
+    With N ranks (torch.distributed.run) the folder holds N x as many frames and rank r takes files r, r + N, ... on its own GPU
+    (weak scaling; no data-path collective, one all_reduce of the counts after the timed region)."""
     import glob
     import shutil
     import tempfile
     import numpy as np
+    import torch.distributed as dist
     from hamer_yolo_amd import infer
     from hamer_yolo_amd.yolo.detector import Detector
 
@@ -108,18 +139,27 @@ def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass
 
     from PIL import Image
     F = args.frames
-    root = tempfile.mkdtemp(prefix="hamer_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    multi = world > 1
+    root_box = [tempfile.mkdtemp(prefix="hamer_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) if rank == 0 else None]
+    if multi:
+        dist.broadcast_object_list(root_box, src=0)
+    root = root_box[0]
     try:
-        in_dir, out_dir = os.path.join(root, "rgb"), os.path.join(root, "out")
-        os.makedirs(in_dir)
-        n_frames = F * chunks_per_pass             # a pass = this many chunks; fill and drain of the two-chunk pipeline are part of it
-        seeded = [synth.frame_u8(1080, 1920, seed=i).numpy() for i in range(8)]
-        for i in range(n_frames):                          # uncompressed .bmp: the decode is a copy, not an inflate
-            dst = os.path.join(in_dir, f"f{i:04d}.bmp")
-            if i < 8:
-                Image.fromarray(seeded[i][:, :, ::-1]).save(dst)
-            else:                                          # the eight seeded frames repeat: hard links, every file is still read and decoded
-                os.link(os.path.join(in_dir, f"f{i % 8:04d}.bmp"), dst)
+        in_dir = os.path.join(root, "rgb")
+        per_rank = F * chunks_per_pass             # frames per rank and pass; fill and drain of the pipeline are part of a pass
+        n_frames = per_rank * world
+
+        def link_frames(lo, hi):
+            for i in range(lo, hi):                # the eight seeded frames repeat: hard links, every file is still read and decoded
+                os.link(os.path.join(in_dir, f"f{i % 8:05d}.bmp"), os.path.join(in_dir, f"f{i:05d}.bmp"))
+
+        if rank == 0:
+            os.makedirs(in_dir)
+            for i in range(8):                     # uncompressed .bmp: the decode is a copy, not an inflate
+                Image.fromarray(synth.frame_u8(1080, 1920, seed=i).numpy()[:, :, ::-1]).save(os.path.join(in_dir, f"f{i:05d}.bmp"))
+            link_frames(8, n_frames)
+        if multi:
+            dist.barrier()
         hi = infer.hamer_inference(HCfg)
         det = Detector(YCfg)
         sar, k_real = None, None
@@ -128,56 +168,96 @@ def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass
             from hamer_yolo_amd.rootnet.Model_RGB import get_model
             sar = get_model()                              # synthetic ResNet-34 + depth head (rootnet/sar_config_stage_1.py)
             k_real = np.array([[1400.0, 0, 960], [0, 1400.0, 540], [0, 0, 1]], np.float32)
+        n_out = [0]
 
-        def step():
-            shutil.rmtree(out_dir, ignore_errors=True)
+        def step(**kw):
+            out_dir = os.path.join(root, f"out_r{rank}_{n_out[0]}")      # (a fresh folder per pass: no deletes inside the timed region)
+            n_out[0] += 1
             if sar is not None:
-                d_infer.process_batch_manopara(in_dir, out_dir, k_real, hamer=hi, detector=det, sar=sar, frames_per_step=F)
-            else:
-                infer.process_batch_manopara(in_dir, out_dir, None, hamer=hi, detector=det, frames_per_step=F)
+                return d_infer.process_batch_manopara(in_dir, out_dir, k_real, hamer=hi, detector=det, sar=sar, frames_per_step=F,
+                                                      rank=rank, world=world, **kw), out_dir
+            return infer.process_batch_manopara(in_dir, out_dir, None, hamer=hi, detector=det, frames_per_step=F,
+                                                rank=rank, world=world, **kw), out_dir
+
+        def timed(n_steps):
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hands = 0
+            for _ in range(n_steps):
+                st, od = step()
+                hands += st["hands"]
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if multi:
+                t = torch.tensor([el, float(hands)], device=dev, dtype=torch.float64)
+                dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+                dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+                el, hands = float(t[0].item()), int(round(float(t[1].item())))
+            return el, hands, st, od
 
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
             for _ in range(max(1, args.warmup)):
                 step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-        # hands per pass: count the detections once more (each .npy keeps only the last hand per label)
-        hands8 = sum(len(d) for fr in range(8) for d in det.detect(seeded[fr])[1])
-        hands = hands8 * (n_frames // 8)
-        files = len(glob.glob(os.path.join(out_dir, "*.npy")))
+            el, hands_all, st, od = timed(args.steps)
+        hands = hands_all // args.steps                        # hands FORWARDED per pass, all ranks (boxes without area never get there)
+        files = len(glob.glob(os.path.join(od, "*.npy")))
+        roof = None
+        if want_roofline and not multi:
+            # the two MFMA kernel families of this workload, each launch timed alone: one pass of the same driver with the
+            # detector on the HaMeR stream and one batch in flight (hipEvent pairs around every launch, hm_prof_*)
+            with contextlib.redirect_stdout(io.StringIO()), L.profile(capacity=1 << 16) as prof:
+                step(in_flight=1, overlap_detector=False)
+                torch.cuda.synchronize()
+            fam = {"gemm": [0.0, 0.0, 0], "conv": [0.0, 0.0, 0]}
+            other = {}
+            for kind, epi, M, N, K, ms in prof.records:
+                if kind in fam:
+                    fam[kind][0] += 2.0 * M * N * K; fam[kind][1] += ms; fam[kind][2] += 1
+                else:
+                    other[kind] = other.get(kind, 0.0) + ms
+            roof = {k: {"achieved": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "launches_per_pass": v[2],
+                        "ms_per_pass": round(v[1], 3), "gflop_per_pass": round(v[0] / 1e9, 1)} for k, v in fam.items() if v[1] > 0}
+            roof["bound"] = "mfma"
+            roof["other_ms_per_pass"] = {k: round(v, 3) for k, v in sorted(other.items(), key=lambda kv: -kv[1])}
+            roof["timing"] = "hipEvent pairs around every launch; one serial pass of the same driver (detector on the HaMeR stream, one batch in flight)"
         long_pass = None
-        if long_chunks > chunks_per_pass:                  # the same models over a longer folder (same eight frames, more links)
+        if long_chunks > chunks_per_pass and not multi:    # the same models over a longer folder (same eight frames, more links)
             n_long = F * long_chunks
-            for i in range(n_frames, n_long):
-                os.link(os.path.join(in_dir, f"f{i % 8:04d}.bmp"), os.path.join(in_dir, f"f{i:04d}.bmp"))
+            link_frames(n_frames, n_long)
             with contextlib.redirect_stdout(io.StringIO()):
                 step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                step(); step()
-                torch.cuda.synchronize()
-                el2 = (time.perf_counter() - t0) / 2
-            long_pass = {"value": round(hands8 * (n_long // 8) / el2, 2), "ms_per_step": round(1e3 * el2, 3), "frames_per_pass": n_long,
-                         "frames_per_s": round(n_long / el2, 2)}
+                el2, hands2, _, _ = timed(2)
+            long_pass = {"value": round(hands2 / el2, 2), "ms_per_step": round(1e3 * el2 / 2, 3), "frames_per_pass": n_long,
+                         "frames_per_s": round(2 * n_long / el2, 2), "hands_per_pass": hands2 // 2}
+        if multi:
+            dist.barrier()
     finally:
-        shutil.rmtree(root, ignore_errors=True)
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
     return           ({"metric": "hands/sec end-to-end (files -> YOLOv7 -> " + ("RootNet depth + " if sar is not None else "") + "crop -> HaMeR -> MANO -> .npy), 1080p frames",
-                      "value": round(hands * args.steps / el, 2), "unit": "hands/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "value": round(hands_all / el, 2), "unit": "hands/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": round(1e3 * el / args.steps, 3), "frames_per_pass": n_frames, "hands_per_pass": hands,
                       "hands_per_frame": round(hands / n_frames, 2), "frames_per_s": round(n_frames * args.steps / el, 2),
-                      "npy_files_per_pass": files, "higher_is_better": True,
+                      "npy_files_per_pass_rank0": files, "higher_is_better": True, "scaling": "weak",
                       "dtype": args.dtype + " (HaMeR) / fp16 (YOLOv7)", "data": "synthetic",
                       "config": {"workload": ("d_infer.py flow: 1080p frames through YOLOv7 + RootNet (ResNet-34 root depth per hand) + HaMeR via "
                                               "d_infer.process_batch_manopara, detector boxes used as found") if sar is not None else
                                              ("BASELINE configs[2]: 1080p frames through yolo/detector.py YOLOv7 + HaMeR via "
                                               "infer.process_batch_manopara (the README entry point), detector boxes used as found"),
-                                 "frames_per_step": F, "chunks_in_flight": 2, "detector_weights": yolo_weights},
-                      "gflop_per_frame": round(61.9 + hands / n_frames * 251.03, 1), **({"long_pass": long_pass} if long_pass else {})})
+                                 "first_detector_pass_frames": F, "detector_pass_frames": infer.DET_FRAMES, "hands_per_forward": infer.HANDS_PER_FORWARD,
+                                 "batches_in_flight": 2, "detector_weights": yolo_weights, "frames_per_rank_and_pass": per_rank,
+                                 "parallelism": f"frames round-robin x{world}", "forwards_per_pass_rank0": st.get("forwards"),
+                                 "detector_passes_per_pass_rank0": st.get("det_passes")},
+                      "gflop_per_frame": round(61.9 + hands / n_frames * 251.03, 1),
+                      **({"roofline": roof} if roof else {}), **({"long_pass": long_pass} if long_pass else {})})
 
 
 E2E_WEIGHTS_4_HANDS = "synthetic:2:-2.53:0"     # objectness bias calibrated on the 8 seeded frames to ~4 boxes per frame (tools/probes/yolo_hands_per_frame.py)
@@ -234,13 +314,19 @@ def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value, ctxs):
     def side_e2e():
         # configs[2]: 1080p frames through the product driver, detector calibrated to ~4 hands per frame
         a2 = types.SimpleNamespace(frames=16, steps=3, warmup=1, workload="e2e", dtype="fp16")
-        r = run_e2e(a2, dev, torch.float16, yolo_weights=E2E_WEIGHTS_4_HANDS, chunks_per_pass=4, long_chunks=12)
-        o = {k: r[k] for k in ("value", "unit", "ms_per_step", "frames_per_pass", "hands_per_frame", "frames_per_s", "npy_files_per_pass",
-                               "dtype", "gflop_per_frame")}
+        r = run_e2e(a2, dev, torch.float16, yolo_weights=E2E_WEIGHTS_4_HANDS, chunks_per_pass=4, long_chunks=12, want_roofline=True)
+        o = {k: r[k] for k in ("value", "unit", "ms_per_step", "frames_per_pass", "hands_per_pass", "hands_per_frame", "frames_per_s",
+                               "npy_files_per_pass_rank0", "dtype", "gflop_per_frame", "roofline")}
+        o["vs_contract_line"] = round(r["value"] / contract_value, 4)
         o["detector_weights"] = E2E_WEIGHTS_4_HANDS
-        # long_pass: the same driver and models over a folder three times as long -- a 64-frame pass spends ~17 of its ~100 ms
-        # filling the pipeline (decode + upload + detector pass of the first chunk with nothing to overlap) and draining it
+        o["pipeline"] = {k: r["config"][k] for k in ("first_detector_pass_frames", "detector_pass_frames", "hands_per_forward",
+                                                     "forwards_per_pass_rank0", "detector_passes_per_pass_rank0")}
+        # long_pass: the same driver and models over a folder three times as long -- a 64-frame pass cannot hide the fill of
+        # the pipeline (decode + upload + detector pass of the first frames with nothing to overlap) and its drain
         o["long_pass"] = r["long_pass"]
+        o["long_pass"]["vs_contract_line"] = round(r["long_pass"]["value"] / contract_value, 4)
+        if not args.no_cpu_baseline:
+            o["cpu_baseline_detector"] = cpu_baseline_detector(E2E_WEIGHTS_4_HANDS)
         return o
 
     for key, name, fn in (("shard", "configs[3] shard1024, N=1", side_shard), ("fp8", "configs[4] fp8 ViT-H, B=256", side_fp8),
@@ -308,7 +394,7 @@ def main():
                          "gathered to rank 0 (strong scaling; a step = the whole 1024-crop job); e2e: configs[2], 1080p frames on "
                          "disk through the product driver infer.process_batch_manopara")
     ap.add_argument("--crops", type=int, default=1024, help="shard1024: crops in the whole job")
-    ap.add_argument("--frames", type=int, default=16, help="e2e: frames per chunk (one YOLOv7 pass and one HaMeR forward each)")
+    ap.add_argument("--frames", type=int, default=16, help="e2e: frames of the first detector pass (later passes take up to 48; HaMeR forwards are 64 hands)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="batches in flight: consecutive forwards alternate between this many HIP streams (own workspace and outputs "
                          "each), so one batch's HBM-bound phases overlap another's MFMA phases; 1 = strictly one after the other; "
@@ -319,7 +405,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=-1, help="force one GEMM tile variant (tuning runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the short runs of the other single-GPU BASELINE configurations ('side_configs')")
-    ap.add_argument("--chunks", type=int, default=4, help="e2e: chunks of --frames frames per pass (a step = one pass over frames x chunks files)")
+    ap.add_argument("--chunks", type=int, default=4, help="e2e: a pass (= a step) covers frames x chunks files per GPU")
     ap.add_argument("--hands4", action="store_true", help="e2e: detector weights calibrated to ~4 hands per frame (configs[2]'s wording) instead of ~8.6")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -339,15 +425,20 @@ def main():
     B = args.batch
 
     if args.workload in ("e2e", "e2e-depth"):
-        print(json.dumps(run_e2e(args, dev, dtype, yolo_weights=E2E_WEIGHTS_4_HANDS if args.hands4 else "synthetic:2:-2.2:0",
-                                 chunks_per_pass=args.chunks)), flush=True)
+        res = run_e2e(args, dev, dtype, yolo_weights=E2E_WEIGHTS_4_HANDS if args.hands4 else "synthetic:2:-2.2:0",
+                      chunks_per_pass=args.chunks, rank=rank, world=world, want_roofline=not args.no_roofline)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(res), flush=True)
         return
 
     # weights: rank 0 draws the synthetic checkpoint (fp32 master weights), RCCL broadcasts it as two flat buffers
     sd0 = synth.hamer_state_dict(cfg, seed=0, device=dev) if rank == 0 else None
     # (fp8: the matrices that become e4m3 travel as fp32 -- quantising a copy already rounded to 16 bits would round twice and
     # make the e4m3 bytes and scales depend on the world size)
-    sd = shard.broadcast_state_dict(sd0, dev, src=0, half_dtype=torch.float32 if args.dtype == "fp8" else dtype) if world > 1 else sd0
+    sd = shard.broadcast_state_dict(sd0, dev, src=0, half_dtype=torch.float32 if args.dtype == "fp8" else dtype) if shard._multi() else sd0
     mano_cpu = synth.mano_params(seed=0)
     eng = HamerEngine(sd, mano_cpu, cfg, device=dev, dtype=dtype, fp8=(args.dtype == "fp8"), fold_ln=args.fold_ln or None,
                       token_merge=True if args.token_merge else None)
@@ -376,7 +467,7 @@ def main():
             nstep[0] += 1
             with torch.cuda.stream(c.stream):
                 eng.forward(img, c.out, workspace=c.workspace)
-                if world > 1:
+                if shard._multi():        # N > 1 (or the HAMER_RCCL_AT_WORLD1=1 opt-in on one GPU): RCCL gather of the MANO parameters
                     shard.gather_mano(shard.pack_mano(c.out), dst=0)
         units_per_step = world * B
     torch.cuda.synchronize()
@@ -480,15 +571,17 @@ def main():
             "ms_per_step_by_kernel": {k: round(v / nprof, 4) for k, v in sorted(by_kind.items(), key=lambda kv: -kv[1])},
             "timing": f"hipEvent pairs around every launch, separate pass of {nprof} steps after the timed region",
         }
-    default_line = (world == 1 and args.workload == "crops" and args.dtype == "fp16" and B == 64 and not args.token_merge
+    if rank == 0 and shard.FORCE_COLLECTIVES:
+        res["config"]["rccl_at_world1"] = "HAMER_RCCL_AT_WORLD1=1: weight broadcast and per-step MANO gather ran through RCCL on one rank"
+    default_line = (world == 1 and not shard.FORCE_COLLECTIVES and args.workload == "crops" and args.dtype == "fp16" and B == 64 and not args.token_merge
                     and not args.fold_ln and args.gemm_variant < 0)
     if rank == 0 and default_line and not args.no_side:
         res["side_configs"] = side_configs(args, dev, cfg, sd, mano_cpu, eng, res["value"], ctxs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, sd, mano_cpu)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
+        shard.shutdown_distributed()
     if rank == 0:
         print(json.dumps(res), flush=True)
 

@@ -14,25 +14,29 @@ from .rootnet.Model_RGB import get_model  # noqa: F401
 
 
 def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None, detector=None, sar=None,
-                           frames_per_step: int = FRAMES_PER_STEP):
+                           frames_per_step: int = FRAMES_PER_STEP, rank=None, world=None, **pipeline):
     """d_infer.py:1223-1318: as infer.py's, with the RootNet depth per hand.  ``k_real`` is required here (the depth is
     metric only with real intrinsics; the reference passes its camera file).  The reference runs one RootNet and one HaMeR
-    forward per hand; here the folder goes through infer.py's chunked two-stream pipeline with ONE RootNet forward and ONE
-    HaMeR forward per chunk of frames -- each hand's camera translation still uses its own depth (``depth_refine`` is a
-    per-hand vector in the camera step), and the numbers are those of the one-hand calls."""
+    forward per hand; here the folder goes through infer.py's pipeline with ONE RootNet forward and ONE HaMeR forward per
+    batch of hands -- each hand's camera translation still uses its own depth (``depth_refine`` is a per-hand vector in the
+    camera step), and the numbers are those of the one-hand calls.  Rank sharding as infer.process_batch_manopara."""
+    from .infer import _rank_world
     os.makedirs(output_folder, exist_ok=True)
     if k_real is None:
         raise ValueError("d_infer needs camera intrinsics (k_real)")
     hamer, detector = _default_models(hamer, detector)
     if sar is None:
         sar = get_model()
+    rank, world = _rank_world(rank, world)
+    stats = {}
     for img_path, detection_list, hands in iter_folder_results(_list_images(input_folder), hamer, detector, k_real, frames_per_step,
-                                                               depth_model=sar):
+                                                               depth_model=sar, rank=rank, world=world, stats=stats, **pipeline):
         file_name = os.path.splitext(os.path.basename(img_path))[0]
         image_results = {'left': None, 'right': None}
         for i, bbox in enumerate(detection_list):
             image_results[bbox[0]] = _record_from(hands, i, bbox[0] == 'right')
         np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
+    return stats
 
 
 def main(argv=None):

@@ -332,13 +332,22 @@ def _detection_list(dets):
 
 
 # The reference walks the folder one image and one hand at a time (infer.py:1248-1316: imread -> detect -> one
-# estimate_from_rgb per hand -> save).  Here the same per-image results come out of a pipeline that keeps the GPU full:
-#   * images are decoded by a thread pool, `frames_per_step` consecutive images of one size form a chunk;
-#   * a chunk is ONE batched YOLOv7 pass + NMS (one host sync for all its box lists), then all hands of all its frames
-#     are cropped into one batch tensor and go through ONE HaMeR forward and one vectorised camera step;
-#   * chunks alternate between two HIP streams, so the detector pass of chunk i+1 runs under the HaMeR forward of chunk i
-#     and the host only waits when it needs the numbers (bench.py --workload e2e times exactly this function).
+# estimate_from_rgb per hand -> save).  Here the same per-image results come out of a pipeline that keeps the GPU full and
+# hands each stage the batch shape it is tuned for (round 4: the two stages no longer share a chunk):
+#   * images are decoded by a thread pool straight into page-locked slots, a rolling window ahead of the GPU;
+#   * DETECTOR PASSES: runs of consecutive frames of one size -- `frames_per_step` for the first pass (so the first HaMeR
+#     forward starts early), up to `det_frames` afterwards (the 12x20 / 24x40 maps of YOLOv7 want many frames per launch) --
+#     go up as one copy and through ONE batched YOLOv7 pass + NMS on the detector's own stream; one host sync per pass
+#     returns all its box lists, and the hands join a queue in (file, detection) order;
+#   * HaMeR BATCHES: whenever `hands_per_forward` hands are queued, exactly that many -- across frame and pass boundaries --
+#     are cropped into one batch tensor (one crop launch per contributing frame) and go through ONE HaMeR forward and one
+#     vectorised camera step, batches alternating between `in_flight` streams; the rest is flushed at the end of the folder;
+#   * a file's result is emitted, in path order, once its last hand has come back.
+# Multi-GPU (SURVEY 8e "frames round-robin per rank, YOLO run where the frame lives"): rank r of `world` takes files
+# r, r + world, ...; every rank runs this whole pipeline on its own GPU and writes its own files -- no data-path collective.
 FRAMES_PER_STEP = 16
+DET_FRAMES = 48
+HANDS_PER_FORWARD = 64
 
 
 def _driver_streams(dev, n: int):
@@ -349,183 +358,336 @@ def _driver_streams(dev, n: int):
     return get_streams(dev, n)
 
 
-class _PinnedFrames:
-    """Page-locked frame slots of one shape for the folder drivers' decoders: file i of a pass decodes into slot i % n, and the
-    upload of a chunk is one asynchronous host -> device copy per frame straight from the slots -- no staging copy (it was 5 ms
-    of a 100 ms pass of 64 frames, with nothing to overlap at the start of a pass).  n covers the decode-ahead window plus three
-    chunks, so a slot is rewritten only after the chunk that used it has been finished (its stream synchronised)."""
-    _cache: Dict = {}
-    _lock = None
+class _Cpu:
+    """Stand-ins for stream / event on a host-only run of the driver (the world_size-2 CPU test drives it with stub models)."""
 
-    def __init__(self, shape, n):
-        self.shape, self.n = tuple(shape), n
-        self.buf = torch.empty((n,) + self.shape, dtype=torch.uint8, pin_memory=True)
-        self.views = self.buf.numpy()
+    class Stream:
+        def synchronize(self): pass
+        def wait_event(self, ev): pass
+        def wait_stream(self, st): pass
 
-    @classmethod
-    def get(cls, shape, n):
+    class Event:
+        def record(self, st=None): pass
+        def synchronize(self): pass
+
+    class ctx:
+        def __init__(self, st): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+
+
+class _FrameRing:
+    """Page-locked frame slots owned by ONE generator: file i decodes into slot i % n, and a detector pass goes up as
+    asynchronous host -> device copies straight from the slots (no staging copy).  Every slot carries the event recorded
+    behind the last copy that read it; a decoder waits for that event before it rewrites the slot, and files are only
+    submitted for decoding once the slot's previous occupant has been uploaded -- so a slot is never rewritten under a
+    pending copy, whatever `in_flight`, pass sizes or window the caller chose.  Nothing is cached at class
+    level: two generators never share slots, and the memory goes back to torch's host allocator with the generator."""
+    MAX_SHAPES = 2                       # a folder of many frame sizes: later sizes decode into ordinary arrays
+
+    def __init__(self, n: int, pin: bool):
         import threading
-        if cls._lock is None:
-            cls._lock = threading.Lock()
-        with cls._lock:
-            ring = cls._cache.get(tuple(shape))
-            if ring is None or ring.n < n:
-                if len(cls._cache) >= 2:                       # (folders of many frame sizes: do not hoard page-locked memory)
-                    cls._cache.clear()
-                ring = cls._cache[tuple(shape)] = cls(shape, n)
-            return ring
+        self.n, self.pin = n, pin
+        self.bufs: Dict = {}
+        self.events: List = [None] * n
+        self.lock = threading.Lock()
+
+    def slot(self, index: int, shape):
+        """(tensor view, numpy view) of file `index`'s slot for frames of `shape`, safe to write; None when out of room."""
+        s = index % self.n
+        ev = self.events[s]
+        if ev is not None:
+            ev.synchronize()
+        shape = tuple(shape)
+        with self.lock:
+            b = self.bufs.get(shape)
+            if b is None:
+                if len(self.bufs) >= self.MAX_SHAPES:
+                    return None
+                t = torch.empty((self.n,) + shape, dtype=torch.uint8, pin_memory=self.pin)
+                b = self.bufs[shape] = (t, t.numpy())
+        return b[0][s], b[1][s]
+
+
+def shard_paths(paths: List[str], rank: int = 0, world: int = 1) -> List[str]:
+    """Rank `rank`'s files of a folder job split over `world` ranks: round robin (r, r + world, ...), so that every rank's
+    share spans the whole sequence and consecutive frames of one camera stay evenly spread."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(paths[rank::world])
 
 
 def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_step: int = FRAMES_PER_STEP, in_flight: int = 2,
-                        decode_threads: Optional[int] = None, depth_model=None):
+                        decode_threads: Optional[int] = None, depth_model=None, hands_per_forward: int = HANDS_PER_FORWARD,
+                        det_frames: Optional[int] = None, rank: int = 0, world: int = 1, stats: Optional[Dict] = None,
+                        overlap_detector: bool = True):
     """Yields ``(path, detection_list, hands)`` per image that has detections, in path order; ``hands`` is a dict of host
     numpy arrays for that image's hands in detection order: betas (n,10), global_orient (n,1,3,3), hand_pose (n,15,3,3),
     cam_t (n,3), do_flip (n,), plus the axis-angle forms pose_global (n,3) and pose_hand (n,45).
-    ``depth_model`` (d_infer): a RootNet ``EstimateRGB``; every hand's root depth comes from ONE RootNet forward per chunk
-    and enters the camera step as its ``depth_refine``; hands without a RootNet patch are dropped, as the reference's
-    per-hand try/except drops them."""
+    ``depth_model`` (d_infer): a RootNet ``EstimateRGB``; every hand's root depth comes from ONE RootNet forward per HaMeR
+    batch and enters the camera step as its ``depth_refine``; hands without a RootNet patch are dropped, as the reference's
+    per-hand try/except drops them.
+    ``rank`` / ``world``: this process handles ``shard_paths(image_paths, rank, world)`` only.
+    ``stats`` (optional dict) receives ``images`` (files of this rank), ``frames`` (files with a result), ``hands`` (hands that
+    went through HaMeR), ``det_passes`` and ``forwards``.
+    ``overlap_detector=False`` puts the detector passes on the first HaMeR stream (with ``in_flight=1``: a strictly serial
+    GPU timeline, what bench.py's per-launch profile pass wants)."""
+    from collections import deque
     from concurrent.futures import ThreadPoolExecutor
-    dev = hamer.device
+    image_paths = shard_paths(list(image_paths), rank, world)
+    dev = torch.device(hamer.device)
+    on_gpu = dev.type == "cuda"
     nthreads = decode_threads or max(1, min(16, len(os.sched_getaffinity(0))))
-    streams = _driver_streams(dev, max(1, in_flight))
+    H = max(1, int(hands_per_forward))
+    first_pass = max(1, int(frames_per_step))
+    big_pass = max(first_pass, int(det_frames) if det_frames else (DET_FRAMES if first_pass >= FRAMES_PER_STEP else first_pass))
+    n_streams = max(1, in_flight)
+    if on_gpu:
+        streams = _driver_streams(dev, n_streams + 1)         # [0 .. in_flight) HaMeR batches, the last one the detector's
+        hstreams, dstream = streams[:n_streams], (streams[n_streams] if overlap_detector else streams[0])
+        new_event, stream_ctx = (lambda: torch.cuda.Event()), torch.cuda.stream
+    else:
+        hstreams, dstream = [_Cpu.Stream() for _ in range(n_streams)], _Cpu.Stream()
+        new_event, stream_ctx = _Cpu.Event, _Cpu.ctx
+    st = stats if stats is not None else {}
+    st.update(images=len(image_paths), frames=0, hands=0, det_passes=0, forwards=0)
 
-    def chunks_of(paths, images):
-        cur, shape = [], None
-        for pth, im in zip(paths, images):
-            if im is None:
-                continue
-            if cur and (im.shape != shape or len(cur) == frames_per_step):
-                yield cur
-                cur = []
-            shape = im.shape
-            cur.append((pth, im))
-        if cur:
-            yield cur
+    ahead = max(4 * first_pass, big_pass + first_pass)                       # decode-ahead window, in files
+    ring = _FrameRing(min(max(1, len(image_paths)), ahead + 2 * big_pass), pin=on_gpu)
+    files: List[Optional[Dict]] = [None] * len(image_paths)        # per file: dets, rows of finished hands, hands still out
+    queue = deque()                                                   # (file index, detection index, frame tensor)
+    det_jobs, batches = deque(), deque()
+    hands_per_frame = 4.0                                             # running estimate, for how far ahead the detector runs
 
-    pinned = {}                       # (stream slot, frame shape) -> page-locked staging buffer of one chunk of frames
-    slot_of = {}                      # id(decoded array) -> its page-locked slot (tensor), for the frames of the current step
+    def decode(index, path):
+        """One file -> (HxWx3 BGR array or None, its page-locked slot as a tensor or None)."""
+        taken = []
 
-    def upload(chunk, slot, pool):
-        """The chunk's frames -> device through a page-locked staging buffer: the copies into it run on the decode pool's
-        threads, the transfer itself is one asynchronous H2D on the chunk's stream (a pageable `.to(device)` per frame
-        costs the host 1-1.5 ms each, in series with everything else it has to do)."""
-        shape = chunk[0][1].shape
-        srcs = [slot_of.get(id(im)) for _, im in chunk]
-        if all(t is not None for t in srcs):               # decoded into page-locked slots: one asynchronous copy per frame
-            d = torch.empty((len(chunk),) + tuple(shape), dtype=torch.uint8, device=dev)
-            for i, t in enumerate(srcs):
-                d[i].copy_(t, non_blocking=True)
-            return [d[i] for i in range(len(chunk))]
-        key = (slot, shape)
-        if key not in pinned:
-            pinned[key] = torch.empty((frames_per_step,) + tuple(shape), dtype=torch.uint8, pin_memory=True)
-        buf = pinned[key]
-        views = buf.numpy()
-
-        def put(i):
-            np.copyto(views[i], chunk[i][1])
-        list(pool.map(put, range(len(chunk))))
-        d = buf[:len(chunk)].to(dev, non_blocking=True)
-        return [d[i] for i in range(len(chunk))]
-
-    def enqueue(chunk, stream, slot=0, pool=None):
-        """Detector pass (+ its one sync), crops, HaMeR forward and camera step of one chunk, all on `stream`."""
-        with torch.cuda.stream(stream):
-            if pool is not None and len(chunk) <= frames_per_step:
-                frames = upload(chunk, slot, pool)
-            else:
-                frames = [torch.from_numpy(np.ascontiguousarray(im)).to(dev) for _, im in chunk]
-            if hasattr(detector, "detect_frames"):
-                _, dets_lists = detector.detect_frames(frames)
-            else:                                              # any object with the reference's detect(image) works too
-                dets_lists = [detector.detect(im)[1] for _, im in chunk]
-            dets_lists = [[d for d in _detection_list(dl) if box_has_area(d)] for dl in dets_lists]
-            if depth_model is not None:
-                for i, (fr, dl) in enumerate(zip(frames, dets_lists)):
-                    ok = depth_model.valid_boxes(dl, int(fr.shape[1]), int(fr.shape[0]))
-                    dets_lists[i] = [d for d, v in zip(dl, ok) if v]
-            keep = [i for i, d in enumerate(dets_lists) if d]
-            if not keep:
+        def alloc(shape):
+            got = ring.slot(index, shape)
+            if got is None:
                 return None
-            depth = None
-            if depth_model is not None:
-                depth = depth_model.estimate_root_depths_frames([frames[i] for i in keep], k_real, [dets_lists[i] for i in keep])
-            out, _ = hamer.estimate_from_frames([frames[i] for i in keep], [dets_lists[i] for i in keep], k_real, depth_refine=depth)
+            taken.append(got[0])
+            return got[1]
+        im = _imread_bgr(path, alloc)
+        if im is not None and not taken:                              # not decoded in place (PIL path): one copy into the slot
+            got = ring.slot(index, im.shape)
+            if got is not None:
+                np.copyto(got[1], im)
+                return got[1], got[0]
+        return im, (taken[0] if taken and im is not None else None)
+
+    # ------------------------------------------------------------------ detector passes
+    def det_enqueue(first, items):
+        """items: [(file index, array, slot tensor or None)] of one frame size -> upload + one batched pass on the detector's
+        stream; returns the job to harvest."""
+        shape = items[0][1].shape
+        with stream_ctx(dstream):
+            if not on_gpu:                                         # (host-only run: the "upload" is a copy out of the ring)
+                frames = [torch.from_numpy(np.array(im, copy=True)) for _, im, _ in items]
+            elif all(t is not None for _, _, t in items):
+                d = torch.empty((len(items),) + tuple(shape), dtype=torch.uint8, device=dev)
+                s0 = items[0][0] % ring.n
+                buf = ring.bufs[tuple(shape)][0]
+                if all(fi % ring.n == s0 + j for j, (fi, _, _) in enumerate(items)):
+                    d.copy_(buf[s0:s0 + len(items)], non_blocking=True)           # consecutive slots: ONE copy for the pass
+                else:
+                    for j, (_, _, t) in enumerate(items):
+                        d[j].copy_(t, non_blocking=True)
+                ev = new_event()
+                ev.record(dstream)
+                for fi, _, _ in items:
+                    ring.events[fi % ring.n] = ev
+                frames = [d[j] for j in range(len(items))]
+            else:
+                frames = [torch.from_numpy(np.ascontiguousarray(im)).to(dev) for _, im, _ in items]
+            if hasattr(detector, "detect_frames_enqueue"):
+                token = detector.detect_frames_enqueue(frames)
+            else:
+                token = None
+            done = new_event()
+            done.record(dstream)
+        st["det_passes"] += 1
+        return {"items": items, "frames": frames, "token": token, "done": done}
+
+    def det_harvest(job):
+        """The pass's one host sync -> box lists -> per-file state + the hand queue."""
+        nonlocal hands_per_frame
+        frames, items = job["frames"], job["items"]
+        with stream_ctx(dstream):
+            if job["token"] is not None:
+                _, dets_lists = detector.detect_frames_finish(job["token"])
+            elif hasattr(detector, "detect_frames"):
+                _, dets_lists = detector.detect_frames(frames)
+            else:                                                  # any object with the reference's detect(image) works too
+                dets_lists = [detector.detect(im)[1] for _, im, _ in items]
+        job["done"].synchronize()        # the pass's uploads and kernels are complete: its frames may be read from any stream
+        found = 0
+        for (fi, _, _), fr, dl in zip(items, frames, dets_lists):
+            dl = [d for d in _detection_list(dl) if box_has_area(d)]
+            if depth_model is not None and dl:
+                ok = depth_model.valid_boxes(dl, int(fr.shape[1]), int(fr.shape[0]))
+                dl = [d for d, v in zip(dl, ok) if v]
+            files[fi] = {"dets": dl, "rows": [None] * len(dl), "out": len(dl)}
+            for j in range(len(dl)):
+                queue.append((fi, j, fr))
+            found += len(dl)
+        hands_per_frame = 0.7 * hands_per_frame + 0.3 * (found / max(1, len(items)))
+
+    def det_one_by_one(items):
+        """A pass that raised: isolate the bad file (the reference's per-file try/except, infer.py:1314-1316)."""
+        for it in items:
+            try:
+                job = det_enqueue(it[0], [it])
+                det_harvest(job)
+            except Exception as e1:
+                print(f"Error processing file {image_paths[it[0]]}: {e1}")
+                files[it[0]] = {"dets": [], "rows": [], "out": 0}
+
+    # ------------------------------------------------------------------ HaMeR batches
+    def batch_enqueue(hands, stream):
+        """`hands`: [(file, detection, frame)] in queue order -> crops, (RootNet,) HaMeR forward and camera step on `stream`.
+        (Their frames are on the device: a hand enters the queue only behind its pass's host sync, see det_harvest.)"""
+        frames, dets_lists = [], []
+        for fi, j, fr in hands:
+            if not frames or frames[-1] is not fr:
+                frames.append(fr); dets_lists.append([])
+            dets_lists[-1].append(files[fi]["dets"][j])
+        with stream_ctx(stream):
+            depth = depth_model.estimate_root_depths_frames(frames, k_real, dets_lists) if depth_model is not None else None
+            out, _ = hamer.estimate_from_frames(frames, dets_lists, k_real, depth_refine=depth)
             mp = out['pred_mano_params']
             dev_res = {'betas': mp['betas'], 'global_orient': mp['global_orient'], 'hand_pose': mp['hand_pose'],
                        'cam_t': out['pred_cam_t_full'], 'do_flip': out['do_flip']}
-            return {'stream': stream, 'paths': [chunk[i][0] for i in keep], 'dets': [dets_lists[i] for i in keep],
-                    'frame_index': out['frame_index'], 'dev': dev_res, 'frames': frames}     # (frames: kept alive until finish)
+        st["forwards"] += 1
+        return {"stream": stream, "hands": [(fi, j) for fi, j, _ in hands], "dev": dev_res, "frames": frames}   # (frames: alive until finish)
 
-    def finish(job):
-        job['stream'].synchronize()
-        res = {k: v.detach().cpu().numpy() for k, v in job['dev'].items()}
+    def batch_finish(job):
+        job["stream"].synchronize()
+        res = {k: v.detach().cpu().numpy() for k, v in job["dev"].items()}
         n = res['betas'].shape[0]
         res['pose_global'] = rodrigues_log_batch(res['global_orient'].reshape(n, 3, 3))
         res['pose_hand'] = rodrigues_log_batch(res['hand_pose'].reshape(n * 15, 3, 3)).reshape(n, 45)
-        fidx = job['frame_index'].numpy()
-        for j, (pth, dets) in enumerate(zip(job['paths'], job['dets'])):
-            sel = np.nonzero(fidx == j)[0]
-            yield pth, dets, {k: v[sel] for k, v in res.items()}
+        for r, (fi, j) in enumerate(job["hands"]):
+            files[fi]["rows"][j] = {k: v[r] for k, v in res.items()}
+            files[fi]["out"] -= 1
+        st["hands"] += n
 
-    with ThreadPoolExecutor(max_workers=nthreads) as pool, ThreadPoolExecutor(max_workers=min(8, nthreads)) as copy_pool:
-        # Decode ahead through a ROLLING window of four chunks: every time a chunk's frames are taken, the window is topped up
-        # by as many files.  (Round 2 submitted the next 4 chunks' files all at once at every fourth chunk: 64 decodes of ~3 ms
-        # bursting onto the host cores the enqueueing thread also needs -- passes of 6-8 chunks ran 15 % slower per chunk than
-        # passes of 4, 5 or 10+.)
-        from collections import deque
-        ahead = frames_per_step * 4
-        futs, submitted = deque(), 0
+    def batch_failed(hands, stream, err):
+        """A batch that raised: redo it frame by frame so that one bad box costs its own frame's hands only."""
+        print(f"Error processing a batch of {len(hands)} hands starting at {image_paths[hands[0][0]]}: {err}")
+        groups = []
+        for h in hands:
+            if not groups or groups[-1][-1][0] != h[0]:
+                groups.append([])
+            groups[-1].append(h)
+        for g in groups:
+            try:
+                batch_finish(batch_enqueue(g, stream))
+            except Exception as e1:
+                print(f"Error processing file {image_paths[g[0][0]]}: {e1}")
+                for fi, j, _ in g:
+                    files[fi]["out"] -= 1                          # (its row stays None: dropped at emission)
 
-        n_slots = min(len(image_paths), ahead + 3 * frames_per_step)
+    emit_at = 0
 
-        def decode(index, path):
-            """One file -> (HxWx3 BGR array, its page-locked slot as a tensor or None)."""
-            taken = []
+    def emit_ready():
+        """Files in path order whose hands have all come back."""
+        nonlocal emit_at
+        while emit_at < len(files) and files[emit_at] is not None and files[emit_at]["out"] == 0:
+            f = files[emit_at]
+            keep = [j for j, r in enumerate(f["rows"]) if r is not None]
+            if keep:
+                hands = {k: np.stack([f["rows"][j][k] for j in keep]) for k in f["rows"][keep[0]]}
+                st["frames"] += 1
+                yield image_paths[emit_at], [f["dets"][j] for j in keep], hands
+            files[emit_at] = {"dets": [], "rows": [], "out": 0}        # (drop the arrays)
+            emit_at += 1
 
-            def alloc(shape):
-                ring = _PinnedFrames.get(shape, n_slots)
-                taken.append(ring.buf[index % ring.n])
-                return ring.views[index % ring.n]
-            im = _imread_bgr(path, alloc if dev.type == "cuda" else None)
-            return im, (taken[0] if taken and im is not None else None)
+    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+        futs, submitted, uploaded, taken = deque(), 0, 0, 0
+        carry = None                                                  # a decoded frame that did not fit the previous pass (other size)
 
-        def top_up(upto):
+        def top_up():
+            # a rolling window: `ahead` files beyond the ones already taken, and never into a slot whose occupant has not gone up
             nonlocal submitted
-            while submitted < min(len(image_paths), upto):
+            while submitted < min(len(image_paths), taken + ahead, uploaded + ring.n):
                 futs.append(pool.submit(decode, submitted, image_paths[submitted]))
                 submitted += 1
 
-        top_up(ahead)
-        pending = []
-        k = 0
-        for st in range(0, len(image_paths), frames_per_step):
-            paths = image_paths[st:st + frames_per_step]
-            decoded = [futs.popleft().result() for _ in paths]
-            images = [d[0] for d in decoded]
-            slot_of.clear()
-            slot_of.update({id(im): t for im, t in decoded if im is not None and t is not None})
-            top_up(st + len(paths) + ahead)
-            for chunk in chunks_of(paths, images):
+        def next_items(limit):
+            """Up to `limit` consecutive decoded frames of one size (unreadable files are skipped with an empty result)."""
+            nonlocal carry, taken
+            items, shape = [], None
+            while len(items) < limit:
+                if carry is not None:
+                    it, carry = carry, None
+                elif taken < len(image_paths):
+                    top_up()
+                    im, slot = futs.popleft().result()
+                    it = (taken, im, slot)
+                    taken += 1
+                    if im is None:
+                        files[it[0]] = {"dets": [], "rows": [], "out": 0}
+                        continue
+                else:
+                    break
+                if items and it[1].shape != shape:
+                    carry = it
+                    break
+                shape = it[1].shape
+                items.append(it)
+            return items
+
+        passes = 0
+        while True:
+            frames_left = carry is not None or taken < len(image_paths)
+            # 1. keep the detector ahead of HaMeR: a pass in flight whenever fewer than ~3 batches of hands are queued or expected
+            expected = len(queue) + sum(len(j["items"]) for j in det_jobs) * hands_per_frame
+            if frames_left and len(det_jobs) < 2 and expected < 3 * H:
+                items = next_items(first_pass if passes == 0 else big_pass)
+                if items:
+                    passes += 1
+                    try:
+                        det_jobs.append(det_enqueue(items[0][0], items))
+                    except Exception as e:
+                        print(f"Error processing a detector pass starting at {image_paths[items[0][0]]}: {e}")
+                        det_one_by_one(items)
+                    uploaded = items[-1][0] + 1
+                    top_up()
+                    continue
+            # 2. full batches as long as the queue holds them; at the end of the folder the remainder (a last batch of up to
+            #    H + H/4 hands rather than a full one and a sliver)
+            draining = not frames_left and not det_jobs
+            while len(batches) < 2 * n_streams and (len(queue) >= H or (draining and queue)):
+                take = len(queue) if (draining and len(queue) <= H + H // 4) else H
+                hands = [queue.popleft() for _ in range(take)]
+                stream = hstreams[st["forwards"] % n_streams]
                 try:
-                    job = enqueue(chunk, streams[k % len(streams)], k % len(streams), copy_pool)   # (own pool: not behind the queued decodes)
-                except Exception as e:                    # isolate the bad file: redo this chunk image by image
-                    print(f"Error processing chunk starting at {chunk[0][0]}: {e}")
-                    job = None
-                    for one in chunk:
-                        try:
-                            j1 = enqueue([one], streams[k % len(streams)])
-                            if j1 is not None:
-                                yield from finish(j1)
-                        except Exception as e1:
-                            print(f"Error processing file {one[0]}: {e1}")
-                k += 1
-                if job is not None:
-                    pending.append(job)
-                while len(pending) >= len(streams):
-                    yield from finish(pending.pop(0))
-        for job in pending:
-            yield from finish(job)
+                    batches.append(batch_enqueue(hands, stream))
+                except Exception as e:
+                    batch_failed(hands, stream, e)
+            # 3. wait where waiting costs least: for the detector when HaMeR has nothing to chew on, else for the oldest batch
+            if det_jobs and (len(queue) < H or not batches):
+                job = det_jobs.popleft()
+                try:
+                    det_harvest(job)
+                except Exception as e:
+                    print(f"Error processing a detector pass starting at {image_paths[job['items'][0][0]]}: {e}")
+                    det_one_by_one(job["items"])
+            elif batches:
+                job = batches.popleft()
+                try:
+                    batch_finish(job)
+                except Exception as e:
+                    hs = [(fi, j, None) for fi, j in job["hands"]]
+                    print(f"Error finishing a batch starting at {image_paths[hs[0][0]]}: {e}")
+                    for fi, j, _ in hs:
+                        files[fi]["out"] -= 1
+                yield from emit_ready()
+            elif not frames_left and not queue:
+                break
+        yield from emit_ready()
 
 
 def _record_from(hands: Dict, i: int, is_right: bool) -> Dict:
@@ -545,31 +707,74 @@ def _default_models(hamer, detector):
     return hamer, detector
 
 
+def _rank_world(rank, world):
+    """(rank, world) of a folder job: explicit arguments win; otherwise the process group when one is initialised (every rank
+    of a torchrun launch then takes its own share of the folder); otherwise the whole folder."""
+    if rank is not None or world is not None:
+        return int(rank or 0), int(world or 1)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_job_stats(stats: Dict) -> Dict:
+    """Every rank's (images, frames, hands) of a sharded folder job -> ``stats['per_rank']`` (a list in rank order) and the
+    ``global_*`` sums, on every rank: ONE all_gather of three integers, after the data path has finished (the job itself has
+    no collective).  A single process gets its own numbers back."""
+    import torch.distributed as dist
+    from . import shard
+    mine = [int(stats.get(k, 0)) for k in ("images", "frames", "hands")]
+    if dist.is_available() and shard._multi():
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor(mine, dtype=torch.int64, device=dev)
+        full = torch.empty(dist.get_world_size() * 3, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(full, t)
+        rows = full.cpu().reshape(-1, 3).tolist()
+    else:
+        rows = [mine]
+    stats["per_rank"] = [{"images": a, "frames": b, "hands": c} for a, b, c in rows]
+    for i, k in enumerate(("images", "frames", "hands")):
+        stats["global_" + k] = sum(r[i] for r in rows)
+    return stats
+
+
 def process_batch_manopara(input_folder, output_folder, k_real=None, hamer=None, detector=None,
-                           frames_per_step: int = FRAMES_PER_STEP):
+                           frames_per_step: int = FRAMES_PER_STEP, rank: Optional[int] = None, world: Optional[int] = None, **pipeline):
     """infer.py:1223-1318: per image, detect -> HaMeR -> save ``<stem>.npy`` holding ``{'left': None|hand, 'right':
     None|hand}`` (the last detection of a label wins, as in the reference's loop); images without detections write nothing.
-    Runs on the chunked two-stream pipeline above: same files, same numbers, the GPU kept busy."""
+    Runs on the pipeline above: same files, same numbers, the GPU kept busy.  Under ``torch.distributed`` (or with explicit
+    ``rank`` / ``world``) every rank processes ``shard_paths(files, rank, world)`` on its own GPU and writes its own files into
+    the same folder; the union is what one process writes.  Returns this rank's ``{'images', 'frames', 'hands', ...}`` counts
+    (the reference returns None)."""
     os.makedirs(output_folder, exist_ok=True)
     hamer, detector = _default_models(hamer, detector)
+    rank, world = _rank_world(rank, world)
     image_paths = _list_images(input_folder)
-    print(f"{len(image_paths)} images")
-    for img_path, detection_list, hands in iter_folder_results(image_paths, hamer, detector, k_real, frames_per_step):
+    print(f"{len(image_paths)} images" + (f" (rank {rank} of {world}: {len(shard_paths(image_paths, rank, world))})" if world > 1 else ""))
+    stats: Dict = {}
+    for img_path, detection_list, hands in iter_folder_results(image_paths, hamer, detector, k_real, frames_per_step,
+                                                               rank=rank, world=world, stats=stats, **pipeline):
         file_name = os.path.splitext(os.path.basename(img_path))[0]
         image_results = {'left': None, 'right': None}
         for i, bbox in enumerate(detection_list):
             image_results[bbox[0]] = _record_from(hands, i, bbox[0] == 'right')
         np.save(os.path.join(output_folder, f"{file_name}.npy"), image_results)
+    return stats
 
 
-def process_batch(input_folder, output_folder, k_real=None, hamer=None, detector=None, frames_per_step: int = FRAMES_PER_STEP):
+def process_batch(input_folder, output_folder, k_real=None, hamer=None, detector=None, frames_per_step: int = FRAMES_PER_STEP,
+                  rank: Optional[int] = None, world: Optional[int] = None, **pipeline):
     """infer.py:908-1036: per detected hand one ``<stem>_<label>[_<n>].npz`` with the ROTATION-MATRIX form of the MANO
     parameters: ``betas (1,10)``, ``global_orient (1,1,3,3)``, ``hand_pose (1,15,3,3)``, ``cam_t (1,3)``, ``is_right``
-    (= do_flip == 0).  A second hand with the same label gets the suffix ``_2``, ``_3`` ... (:996-998).  Same pipeline as
-    process_batch_manopara; the saved arrays are the per-hand slices the reference's one-hand calls produce."""
+    (= do_flip == 0).  A second hand with the same label gets the suffix ``_2``, ``_3`` ... (:996-998).  Same pipeline and
+    rank sharding as process_batch_manopara; the saved arrays are the per-hand slices the reference's one-hand calls produce."""
     os.makedirs(output_folder, exist_ok=True)
     hamer, detector = _default_models(hamer, detector)
-    for img_path, detection_list, hands in iter_folder_results(_list_images(input_folder), hamer, detector, k_real, frames_per_step):
+    rank, world = _rank_world(rank, world)
+    stats: Dict = {}
+    for img_path, detection_list, hands in iter_folder_results(_list_images(input_folder), hamer, detector, k_real, frames_per_step,
+                                                               rank=rank, world=world, stats=stats, **pipeline):
         file_name = os.path.splitext(os.path.basename(img_path))[0]
         saved_counts = {'left': 0, 'right': 0}
         for i, bbox in enumerate(detection_list):
@@ -582,6 +787,7 @@ def process_batch(input_folder, output_folder, k_real=None, hamer=None, detector
                      hand_pose=hands['hand_pose'][i:i + 1], cam_t=hands['cam_t'][i:i + 1],
                      is_right=bool(hands['do_flip'][i] == 0))
             saved_counts[hand_label] += 1
+    return stats
 
 
 def get_bbox_from_npy(npy_path, target_val=3):
@@ -719,9 +925,21 @@ def main(argv=None):
     if args.yolo_weights:
         from .config.yolo_config import yolo_opt
         yolo_opt.weights = args.yolo_weights
+    # under `python -m torch.distributed.run --nproc-per-node N -m hamer_yolo_amd.infer ...` every rank takes its share of
+    # the folder on its own GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment); a plain launch is one process
+    from . import shard
+    rank, local, world = shard.init_distributed()
+    if world > 1 and torch.cuda.is_available():
+        torch.cuda.set_device(local)
     hamer = hamer_inference(hamer_opt)
-    process_batch_manopara(args.input, args.output, k_real, hamer=hamer)
-    if args.obj:
+    stats = process_batch_manopara(args.input, args.output, k_real, hamer=hamer, rank=rank, world=world)
+    if world > 1:
+        gather_job_stats(stats)
+        if rank == 0:
+            print(f"{stats['global_frames']} files, {stats['global_hands']} hands over {world} ranks: {stats['per_rank']}")
+        import torch.distributed as dist
+        dist.barrier()
+    if args.obj and rank == 0:
         reconstruct_and_save_obj_with_wrapper(args.output, args.obj, hamer)
 
 

@@ -20,12 +20,23 @@ GEMM_WEIGHT_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight",
                         "fn.to_kv.weight")
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
+# Opt-in: run the collectives even when the group has ONE rank.  A one-GPU box can then push the real buffers (the 1.3 GB
+# flat weight broadcast, the MANO gather) through RCCL itself -- init_process_group("nccl"), broadcast, all_gather_into_tensor
+# -- instead of taking the single-process shortcut (tests/test_gpu_shard.py; `HAMER_RCCL_AT_WORLD1=1 python bench.py`).
+FORCE_COLLECTIVES = False
+
+
+def init_distributed(backend: Optional[str] = None, force: Optional[bool] = None) -> Tuple[int, int, int]:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract).  A process group is created
+    when WORLD_SIZE > 1 -- or, with ``force`` (default: HAMER_RCCL_AT_WORLD1=1), at world size 1 too, in which case every
+    collective of this module runs through the backend instead of being skipped."""
+    global FORCE_COLLECTIVES
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("HAMER_RCCL_AT_WORLD1", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -33,7 +44,16 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if force and world == 1:
+        FORCE_COLLECTIVES = True
     return rank, local, world
+
+
+def shutdown_distributed() -> None:
+    global FORCE_COLLECTIVES
+    FORCE_COLLECTIVES = False
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -44,7 +64,7 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def _multi() -> bool:
-    return dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], device, src: int = 0,

@@ -95,6 +95,34 @@ class Detector():
         return [det], [self._labelled(det.tolist())]
 
     @torch.no_grad()
+    def detect_frames_enqueue(self, frames):
+        """First half of ``detect_frames`` for callers that keep several passes in flight (the folder drivers): the batched
+        pass, NMS and an asynchronous copy of every frame's box rows and counts into page-locked host memory of THIS call, all
+        on the current stream, no host sync.  The plan's device buffers are shared by every pass of that shape, so a later
+        pass on the same stream may overwrite them; the host copy is what ``detect_frames_finish`` reads."""
+        opt = self.opt
+        p = self.engine.forward(list(frames))
+        self.engine.nms_enqueue(p, opt.conf_thres, opt.iou_thres, opt.classes, opt.agnostic_nms, scale=True)
+        nb = p["nb"]
+        counts = torch.empty(nb, dtype=torch.int32, pin_memory=True)
+        rows = torch.empty(nb * 300, 6, dtype=torch.float32, pin_memory=True)
+        counts.copy_(p["count"], non_blocking=True)
+        rows.copy_(p["dets"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return counts, rows, ev, nb
+
+    def detect_frames_finish(self, token):
+        """Second half: wait for that pass (its event only) and return (preds, dets_lists) as ``detect_frames`` does, the
+        prediction rows as host tensors."""
+        counts, rows, ev, nb = token
+        ev.synchronize()
+        k = counts.tolist()
+        rows = rows.reshape(nb, 300, 6)
+        return ([rows[i, :int(n)].clone() for i, n in enumerate(k)],
+                [self._labelled(rows[i, :int(n)].tolist()) for i, n in enumerate(k)])
+
+    @torch.no_grad()
     def detect_frames(self, frames):
         """``detect`` for a list of equally sized (H,W,3) uint8 BGR DEVICE frames: one batched pass through the network, one
         NMS launch per frame, ONE host transfer for all box lists.  Returns (preds, dets_lists) with one entry per frame, each

@@ -78,7 +78,9 @@ class YoloEngine:
         """Plan for `nb` frames of size HxW processed as one batch (every conv launch covers all of them)."""
         key = (H, W, nb)
         if key in self._plans:
+            self._plans[key] = self._plans.pop(key)           # (most recently used last)
             return self._plans[key]
+        self._evict_plans()
         lib = self.lib
         lp = L.LetterboxPlan()
         L.check(lib.hm_letterbox_plan_make(H, W, self.new_shape, self.stride, C.byref(lp)), "hm_letterbox_plan_make")
@@ -247,6 +249,22 @@ class YoloEngine:
         }
         self._plans[key] = plan
         return plan
+
+    PLAN_BYTES_BUDGET = 32 << 30      # arenas of cached plans (a 48-frame 1080p plan is ~7 GB; the folder drivers' last pass may be any size)
+
+    def _evict_plans(self) -> None:
+        """Before a NEW plan is built: drop the least recently used plans while the cached arenas exceed the budget (the two
+        most recent always stay).  A dropped arena may still be read by queued kernels, so the device is synchronised first --
+        this runs once per new (size, frame count), never in steady state."""
+        total = sum(int(p["arena"].numel()) for p in self._plans.values())
+        if total <= self.PLAN_BYTES_BUDGET or len(self._plans) <= 2:
+            return
+        torch.cuda.synchronize(self.device)
+        for key in list(self._plans)[:-2]:
+            if total <= self.PLAN_BYTES_BUDGET:
+                break
+            total -= int(self._plans[key]["arena"].numel())
+            del self._plans[key]
 
     def layer_output(self, p: dict, i: int) -> torch.Tensor:
         """(C, H, W) fp32 copy of layer i's output inside the arena (debug / tests)."""
