@@ -1406,6 +1406,339 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   }
 }
 
+#ifdef HM_ABLATIONS
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4 EXPERIMENT (experiments library only, -DHM_ABLATIONS; tests opt-in): gemm_px_kernel with a SOFTWARE-PIPELINED K loop
+// (variant 27, gemm_pp_kernel; 33 = the same with the copies of waves 4..7 issued four groups after those of waves 0..3).
+// Bit-identical to variant 26 and NOT faster: interleaved A/B on one box (profiles/r04_gemm_pipelined_ab.log), store epilogue,
+// B = 64: qkv 122.0 us (26) / 123.2 (27) / 132.4 (33), fc1 144.1 / 147.7 / 154.2, fc2 130.9 / 135.4 / 140.0, kv 172.6 / 178.6 /
+// 184.4 -- the reasoning below (which the loop's ISA confirms: no MFMA waits for a fragment any more) predicted a third off the
+// K loop; the measurement says the fragment reads were never what the loop waited for.  With rounds 1-3 (ring depth, tile
+// shapes, wave counts, stagger, no-wait ablations) every structure lands on ~1.5 us per K-step on random operands: the guide's
+// own 256 x 256 template rate, and the rate at which the chip holds its clock down under MFMA + LDS-DMA load (DVFS give-back).
+// What the px / x3 loops do per K-step and wave, as hipcc emits them: [barrier] 12 ds_read_b128, lgkmcnt(3..0), 32 MFMAs,
+// 8 copies, 12 ds_read_b128, wait, 32 MFMAs.  All eight waves leave the barrier together, so all of them read while both
+// MFMA pipes of every SIMD idle, then all of them multiply while the LDS idles: 2 x (96 reads x 4 cycles + latency) + 2 x 1024
+// MFMA cycles per SIMD = ~3050 cycles per step where the MFMAs alone need 2048 (v_mfma 16x16x32: 16 cycles, 64 per wave, two
+// waves per SIMD) -- the 1.5 us per step that every tile structure of rounds 1-3 landed on.  Here the fragment reads never
+// wait in front of the MFMAs that use them:
+//   * a K-step is 16 GROUPS of 4 MFMAs (ks = g >> 3, ni = g & 7: W fragment (ks, ni) against the four X fragments of ks);
+//   * fragment reads are issued from inline asm FIVE groups ahead of their use (W: an 8-entry register ring, slot = ni; X: two
+//     sets of four, one per ks) and waited for by COUNT (LDS operations retire in order; the counts are derived below);
+//   * the step's barrier moves from its top to group 12: by then every read of the step has been issued and is retired by one
+//     lgkmcnt(0), so after the barrier the step's LDS slots are free -- the copies W(t+2), X(t+3) go out there, two pieces per
+//     group over groups 12..15, and the first fragments of step t+1 (whose copies the same wait + barrier have completed) are
+//     requested under the last 16 MFMAs of step t.  W therefore runs TWO steps ahead as well (px: one), in the same two slots.
+//   * last step of a tile: no reads and no copies behind the barrier; after the epilogue (which stages through this wave's own
+//     4 KB of the step's X slot and keeps its bias in its own 4 KB of the W slot -- exactly the regions this wave's next copies
+//     overwrite) the copies, the next tile's bias request and its first nine reads are issued in the order the steady state
+//     uses, so every group's wait count is the same in every step.
+// Read stream of a step (L_g = reads issued in front of group g) and the count each group waits with (reads issued after the
+// last one it needs, through L_g):
+//   L0 W5 | L1 W6 | L2 W7 X1a | L3 W8 X1b | L4 W9 X1c | L5 W10 X1d | L6 W11 | L7 W12 | L8 W13 | L9 W14 | L10 W15 | L11 - |
+//   [lgkmcnt(0) vmcnt barrier] L12 nW0 nW1 nX0a | L13 nW2 nX0b nX0c | L14 nW3 nX0d | L15 nW4
+//   g0 2 (needs nX0d) | g1 9 | g2 9 | g3 8 | g4 8 | g5 9 | g6 9 | g7 9 | g8 3 (needs X1d) | g9 7 | g10 6 | g11 4 | g12 3 | g13 6 | g14 8 | g15 9
+// vmcnt: copies retire in issue order: W then X, always.  At group 12 of step t everything but X(t+2) must have landed:
+// vmcnt(4); in the first step of a tile the tile's two bias loads are younger than X(t+2): vmcnt(6); vmcnt(0) once no X(t+2)
+// exists.  The epilogue's 16 stores are older than the copies issued behind it and retire with them.
+constexpr int pp_wait_count(int g) {
+  constexpr int c[16] = {2, 9, 9, 8, 8, 9, 9, 9, 3, 7, 6, 4, 3, 6, 8, 9};
+  return c[g];
+}
+
+template <class T, int EPI, bool DIRECT = true, bool STAG = false>   // STAG: waves 4..7 issue a step's copies four groups later than waves 0..3 (groups 0..3 of the next step)
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const KArgs g) {
+  static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
+  constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
+  constexpr int TILE_BYTES = 256 * ROWB;                               // 32 KB
+  constexpr int XRING = 0, WRING = 3 * TILE_BYTES;
+  constexpr int XI = 4, WI = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using vec8 = typename T::vec8;
+  using elem = typename T::elem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = g.N >> 8, tiles_m = g.M >> 8, tiles = tiles_m * tiles_n;
+  const int G = gridDim.x, xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per = G >> 3;
+  const int tq = tiles >> 3, tr = tiles & 7;
+  const int run_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_len = tq + (xcd < tr ? 1 : 0);
+  const int my = li < run_len ? (run_len - li + per - 1) / per : 0;
+  if (my == 0) return;
+  const int nk = g.K / 64, S = my * nk;
+  const int wr = wave / WN, wc = wave % WN;
+  const char* X = (const char*)g.X;
+  const char* W = (const char*)g.W;
+
+  const int srow = lane >> 3, swz = (lane & 7) ^ (srow & 7);
+  // lane part of a copy's source address (piece 0 of this wave); the piece index and the tile origin ride in the scalar base
+  const unsigned xoff0 = (unsigned)(wave * XI * 8 + srow) * (unsigned)(g.ldx * 2) + swz * 16;
+  const unsigned woff0 = (unsigned)(wave * WI * 8 + srow) * (unsigned)(g.ldw * 2) + swz * 16;
+  const size_t xpiece = (size_t)8 * g.ldx * 2, wpiece = (size_t)8 * g.ldw * 2;
+  auto origin = [&](int ti, int& m0, int& n0) {
+    int tm, tn;
+    tile_coords(run_lo + li + ti * per, tiles_m, tiles_n, g.group_m, tm, tn);
+    m0 = tm << 8; n0 = tn << 8;
+  };
+  // cursors over the concatenated step sequence: W runs two steps ahead of the MFMAs, X three (one copy cursor each)
+  int xti = 0, xkt = 0, wti = 0, wkt = 0, m0, n0;
+  origin(0, m0, n0);
+  const char* xbase = X + (size_t)m0 * g.ldx * 2;
+  const char* wbase = W + (size_t)n0 * g.ldw * 2;
+  auto next_x = [&]() {
+    if (++xkt == nk) {
+      xkt = 0;
+      if (++xti < my) { int a, b; origin(xti, a, b); xbase = X + (size_t)a * g.ldx * 2; }
+    }
+  };
+  auto next_w = [&]() {
+    if (++wkt == nk) {
+      wkt = 0;
+      if (++wti < my) { int a, b; origin(wti, a, b); wbase = W + (size_t)b * g.ldw * 2; }
+    }
+  };
+  auto piece_x = [&](int slot, int i) {
+    glds16_hidden_s(xbase + (size_t)xkt * ROWB + i * xpiece, xoff0, smem + XRING + slot * TILE_BYTES + wave * XI * 1024 + i * 1024);
+  };
+  auto piece_w = [&](int slot, int i) {
+    glds16_hidden_s(wbase + (size_t)wkt * ROWB + i * wpiece, woff0, smem + WRING + slot * TILE_BYTES + wave * WI * 1024 + i * 1024);
+  };
+
+  // fragment read addresses: X (ks, mi) = X slot + lx[ks] + mi * 2048, W (ks, ni) = W slot + lw[ks] + ni * 2048 (immediates)
+  const int frow = lane & 15, fsw = lane & 7, fch = lane >> 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned lx[2], lw[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    lx[ks] = lds0 + XRING + (unsigned)((wr * 16 * MI + frow) * ROWB + (((ks * 4 + fch) ^ fsw) << 4));
+    lw[ks] = lds0 + WRING + (unsigned)((wc * 16 * NI + frow) * ROWB + (((ks * 4 + fch) ^ fsw) << 4));
+  }
+
+  f32x4_t acc[NI][MI];
+  vec8 wf[NI], xf[2][MI];
+#define PP_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  // the nine reads that open a step, in the order the steady state issues them behind its barrier (nW0 nW1 nX0a | nW2 nX0b nX0c
+  // | nW3 nX0d | nW4): part 0..3 = what groups 12..15 of the previous step carry
+  auto open_reads = [&](auto part, unsigned ax0, unsigned aw0) {
+    constexpr int P = decltype(part)::value;
+    if constexpr (P == 0) { PP_RD(wf[0], aw0, 0); PP_RD(wf[1], aw0, 2048); PP_RD(xf[0][0], ax0, 0); }
+    if constexpr (P == 1) { PP_RD(wf[2], aw0, 4096); PP_RD(xf[0][1], ax0, 2048); PP_RD(xf[0][2], ax0, 4096); }
+    if constexpr (P == 2) { PP_RD(wf[3], aw0, 6144); PP_RD(xf[0][3], ax0, 6144); }
+    if constexpr (P == 3) { PP_RD(wf[4], aw0, 8192); }
+  };
+
+  // prologue: X(0), W(0), X(1) -> wait for the first two -> barrier -> W(1), X(2) -> bias request -> the first nine reads
+  int gs = 0, xs = 0;                                  // global step, its X slot (gs % 3); W slot = gs & 1
+#pragma unroll
+  for (int i = 0; i < XI; ++i) piece_x(0, i);
+  next_x();
+#pragma unroll
+  for (int i = 0; i < WI; ++i) piece_w(0, i);
+  next_w();
+#pragma unroll
+  for (int i = 0; i < XI; ++i) piece_x(1, i);
+  next_x();
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (1 < S) {
+#pragma unroll
+    for (int i = 0; i < WI; ++i) piece_w(1, i);
+    next_w();
+  }
+  if (2 < S) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) piece_x(2, i);
+    next_x();
+  }
+
+  for (int ti = 0; ti < my; ++ti) {
+    if (ti > 0) origin(ti, m0, n0);
+    // this wave's 128 bias values, two per lane (see gemm_px_kernel): always issued, from asm, fenced in front of the epilogue
+    float bias_lo, bias_hi;
+    {
+      const float* bsrc = g.bias ? g.bias + n0 + wc * 128 : (const float*)g.W;
+      asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:256"
+                   : "=&v"(bias_lo), "=&v"(bias_hi) : "v"(lane * 4), "s"(bsrc) : "memory");
+    }
+    {
+      const unsigned ax0 = lx[0] + (unsigned)(xs * TILE_BYTES), aw0 = lw[0] + (unsigned)((gs & 1) * TILE_BYTES);
+      open_reads(std::integral_constant<int, 0>{}, ax0, aw0); open_reads(std::integral_constant<int, 1>{}, ax0, aw0);
+      open_reads(std::integral_constant<int, 2>{}, ax0, aw0); open_reads(std::integral_constant<int, 3>{}, ax0, aw0);
+    }
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int xs_last = 0, ws_last = 0;
+    // one K-step; `last` (the tile's last step) is a compile-time property: behind its barrier there are no reads and no copies,
+    // and a runtime branch around asm statements that define fragment registers costs register copies in every group
+    auto step = [&](auto last_c, const int kt) {
+      constexpr bool last = decltype(last_c)::value;
+      const int ws = gs & 1;
+      const unsigned ax1 = lx[1] + (unsigned)(xs * TILE_BYTES);
+      const unsigned aw0 = lw[0] + (unsigned)(ws * TILE_BYTES), aw1 = lw[1] + (unsigned)(ws * TILE_BYTES);
+      const int xsn = xs == 2 ? 0 : xs + 1;
+      const unsigned nax0 = lx[0] + (unsigned)(xsn * TILE_BYTES), naw0 = lw[0] + (unsigned)((ws ^ 1) * TILE_BYTES);
+      auto group = [&](auto gc) {
+        constexpr int GI = decltype(gc)::value, ks = GI >> 3, ni = GI & 7;
+        // ---- reads (and, behind the barrier, copies) issued in front of this group
+        if constexpr (GI <= 10) {                                     // W fragment five groups on (same step)
+          constexpr int j = GI + 5, jks = j >> 3, jni = j & 7;
+          if constexpr (jks == 0) PP_RD(wf[jni], aw0, jni * 2048); else PP_RD(wf[jni], aw1, jni * 2048);
+        }
+        if constexpr (GI >= 2 && GI <= 5) PP_RD(xf[1][GI - 2], ax1, (GI - 2) * 2048);     // X fragments of ks = 1
+        if constexpr (GI == 12) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every fragment read of this step has returned
+          if (gs + 1 < S) {
+            if (gs + 2 >= S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (kt == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // X(gs+2) and the tile's bias pair may stay in flight
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // X(gs+2)
+          }
+          __builtin_amdgcn_s_barrier();      // step gs+1 complete in LDS; nobody reads step gs's slots any more
+        }
+        if constexpr (GI >= 12) {
+          if constexpr (!last) {
+            // copies into the slots this step just gave up: W(gs+2) -> its W slot, X(gs+3) -> its X slot; two pieces per group
+            if (!STAG || wave < 4) {
+              if constexpr (GI == 12 || GI == 13) {
+                if (gs + 2 < S) { piece_w(ws, 2 * (GI - 12)); piece_w(ws, 2 * (GI - 12) + 1); if constexpr (GI == 13) next_w(); }
+              } else {
+                if (gs + 3 < S) { piece_x(xs, 2 * (GI - 14)); piece_x(xs, 2 * (GI - 14) + 1); if constexpr (GI == 15) next_x(); }
+              }
+            }
+            open_reads(std::integral_constant<int, GI - 12>{}, nax0, naw0);     // the first fragments of step gs + 1
+          }
+        }
+        if constexpr (STAG && GI <= 3) {
+          // waves 4..7: the copies of the step before this one (its barrier has passed), unless that step was a tile's last
+          // (kt == 0: everyone issued those behind the epilogue).  Same issue order per wave, so the counted waits do not change.
+          if (wave >= 4 && kt > 0) {
+            const int wprev = ws ^ 1, xprev = xs == 0 ? 2 : xs - 1;
+            if constexpr (GI <= 1) {
+              if (gs + 1 < S) { piece_w(wprev, 2 * GI); piece_w(wprev, 2 * GI + 1); if constexpr (GI == 1) next_w(); }
+            } else {
+              if (gs + 2 < S) { piece_x(xprev, 2 * (GI - 2)); piece_x(xprev, 2 * (GI - 2) + 1); if constexpr (GI == 3) next_x(); }
+            }
+          }
+        }
+        // ---- wait for this group's fragments by count, naming them so that no MFMA below can move above the wait
+        {
+          vec8 &w = wf[ni], &x0 = xf[ks][0], &x1 = xf[ks][1], &x2 = xf[ks][2], &x3 = xf[ks][3];
+          if constexpr (ni == 0) {                                    // the group that opens a sub-step also releases its X set
+            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(w), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "n"(pp_wait_count(GI)));
+          } else if constexpr (GI >= 12 && last) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w) : "n"(pp_wait_count(GI)));
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[ks][mi], acc[ni][mi]);
+      };
+      group(std::integral_constant<int, 0>{}); group(std::integral_constant<int, 1>{}); group(std::integral_constant<int, 2>{});
+      group(std::integral_constant<int, 3>{}); group(std::integral_constant<int, 4>{}); group(std::integral_constant<int, 5>{});
+      group(std::integral_constant<int, 6>{}); group(std::integral_constant<int, 7>{}); group(std::integral_constant<int, 8>{});
+      group(std::integral_constant<int, 9>{}); group(std::integral_constant<int, 10>{}); group(std::integral_constant<int, 11>{});
+      group(std::integral_constant<int, 12>{}); group(std::integral_constant<int, 13>{}); group(std::integral_constant<int, 14>{});
+      group(std::integral_constant<int, 15>{});
+      xs_last = xs; ws_last = ws;
+      xs = xsn;
+      ++gs;
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) step(std::false_type{}, kt);
+    step(std::true_type{}, nk - 1);
+    // (no barrier here: the one at group 12 of the last step already separates every wave's last reads of these slots from the
+    // staging below.)  Fence of the bias pair, as in gemm_px_kernel: at most 8 copies are in flight, so it never stalls.
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(bias_lo), "+v"(bias_hi) :: "memory");
+
+    // ---- epilogue (gemm_px_kernel's, with the bias in THIS wave's 4 KB of the last step's W slot)
+    // (the epilogue's lane constants are re-derived from an opaque copy of the lane id: hoisted out of the tile loop they would
+    //  live through the K loop, whose 192 accumulator + fragment registers leave no room -- hipcc spilled two of them)
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    float* cb = (float*)(smem + WRING + ws_last * TILE_BYTES + wave * 4096);
+    cb[elane] = g.bias ? bias_lo : 0.f; cb[64 + elane] = g.bias ? bias_hi : 0.f;
+    char* wl = smem + XRING + xs_last * TILE_BYTES + wave * 4096;
+    const int arow = elane & 15, apiece = elane >> 4, row0 = elane >> 2, j = elane & 3;
+    const int mb = m0 + wr * 64, nb = n0 + wc * 128;
+    if constexpr (DIRECT) {
+      const int g4 = elane >> 4;
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      f32x4_t bv[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bv[ni] = *(const f32x4_t*)(cb + ni * 16 + 4 * g4);
+      elem* crow = (elem*)g.C + (size_t)(mb + arow) * g.ldc + nb + (g4 & 1) * 16 + (g4 >> 1) * 8;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int np = 0; np < NI / 2; ++np) {
+          unsigned pk[2][2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4_t a = acc[2 * np + h][mi], bb = bv[2 * np + h];
+            float v0 = __fadd_rn(a[0], bb[0]), v1 = __fadd_rn(a[1], bb[1]), v2 = __fadd_rn(a[2], bb[2]), v3 = __fadd_rn(a[3], bb[3]);
+            if constexpr (EPI == HM_EPI_GELU) {
+              const f32x2_t g0 = gelu_fast2(f32x2_t{v0, v1}), g1 = gelu_fast2(f32x2_t{v2, v3});
+              v0 = g0[0]; v1 = g0[1]; v2 = g1[0]; v3 = g1[1];
+            }
+            typename T::vec4 o;
+            o[0] = (elem)v0; o[1] = (elem)v1; o[2] = (elem)v2; o[3] = (elem)v3;
+            const u32x2 w = __builtin_bit_cast(u32x2, o);
+            pk[h][0] = w[0]; pk[h][1] = w[1];
+          }
+          const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          *(u32x4*)(crow + (size_t)(mi * 16) * g.ldc + np * 32) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+    } else {
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) {
+        const f32x4_t b0 = *(const f32x4_t*)(cb + cg * 32 + 8 * j), b1 = *(const f32x4_t*)(cb + cg * 32 + 8 * j + 4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+              const int row = mm * 16 + arow;
+              *(f32x4_t*)(wl + row * 128 + (((nl * 4 + apiece) ^ (row & 7)) << 4)) = acc[cg * 2 + nl][half * 2 + mm];
+            }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int row = it * 16 + row0, sw = row & 7;
+            const f32x4_t v0 = *(const f32x4_t*)(wl + row * 128 + (((2 * j) ^ sw) << 4));
+            const f32x4_t v1 = *(const f32x4_t*)(wl + row * 128 + (((2 * j + 1) ^ sw) << 4));
+            vec8 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float a = __fadd_rn(v0[q], b0[q]), b = __fadd_rn(v1[q], b1[q]);
+              if constexpr (EPI == HM_EPI_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0]; b = gq[1]; }
+              o[q] = (elem)a; o[4 + q] = (elem)b;
+            }
+            *(vec8*)((elem*)g.C + (size_t)(mb + half * 32 + row) * g.ldc + nb + cg * 32 + 8 * j) = o;
+          }
+        }
+      }
+    }
+    // the copies the last step held back: W(gs+1) .. wait: gs already counts the next step.  W(gs + 1), X(gs + 2) in the numbering
+    // of the step that just ended + 1: the slots of the tile's last step (ws_last, xs_last), whose staging this wave has finished
+    // (its LDS reads returned before the stores that carry their data were issued)
+    if (gs + 1 < S) {
+#pragma unroll
+      for (int i = 0; i < WI; ++i) piece_w(ws_last, i);
+      next_w();
+    }
+    if (gs + 2 < S) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) piece_x(xs_last, i);
+      next_x();
+    }
+  }
+#undef PP_RD
+}
+
+#endif  // HM_ABLATIONS (variants 27 / 33)
+
 // Default persistent grid: one workgroup per CU on all but ONE CU of every XCD (248 of 256; see launch_px), unless all 256 save
 // a whole round of tiles (1020 tiles = fc1 at 68 hands: 4 rounds instead of 5).
 int px_default_grid(int tiles, int cus) {
@@ -1437,7 +1770,7 @@ int px_grid_for(int tiles, int cus) {
 }
 extern "C" int hm_gemm_px_grid(int tiles, int cus) { return px_grid_for(tiles, cus > 0 ? cus : 256); }
 
-template <class T, int EPI>
+template <class T, int EPI, int PIPE = 0>      // PIPE: 1 = the software-pipelined K loop (gemm_pp_kernel), 2 = with the copy stagger between the wave halves
 int launch_px(const KArgs& g, hipStream_t s) {
   constexpr int LDS = 5 * 256 * 128;
   // Epilogue form.  Both are bit-identical; measured in one process (profiles/r03_gemm_px_epilogue_ab.log): the lane-swap form
@@ -1445,9 +1778,16 @@ int launch_px(const KArgs& g, hipStream_t s) {
   // and 3 % slower for the plain store (qkv 119.8 vs 116.4, kv 177.2 vs 170.9) -- so each epilogue takes its faster form.
   // HM_OPT_PX_LDS_EPILOGUE: 0 = that choice, 1 = always through LDS, 2 = always lane swaps.
   const int form = hm_option(HM_OPT_PX_LDS_EPILOGUE);
-  const bool staged = form == 1 || (form == 0 && EPI != HM_EPI_GELU);
+  const bool staged = form == 1 || (form == 0 && (PIPE || EPI != HM_EPI_GELU));   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
+#ifdef HM_ABLATIONS
+  auto kern = PIPE == 2 ? (staged ? gemm_pp_kernel<T, EPI, false, true> : gemm_pp_kernel<T, EPI, true, true>)
+            : PIPE ? (staged ? gemm_pp_kernel<T, EPI, false> : gemm_pp_kernel<T, EPI, true>)
+                   : (staged ? gemm_px_kernel<T, EPI, false> : gemm_px_kernel<T, EPI, true>);
+#else
+  static_assert(PIPE == 0, "the pipelined K loop is an experiment (-DHM_ABLATIONS)");
   auto kern = staged ? gemm_px_kernel<T, EPI, false> : gemm_px_kernel<T, EPI, true>;
-  static HmLdsOnce lds_once[2];
+#endif
+  static HmLdsOnce lds_once[2];      // (per instantiation of this launcher: one pair per (T, EPI, PIPE))
   if (const int rc = lds_once[staged ? 1 : 0].ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
   const int tiles = (g.M >> 8) * (g.N >> 8);
   int cus = hm_device_cu_count();
@@ -1969,6 +2309,17 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
       return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
 #ifdef HM_ABLATIONS
     // ---- experiments (correct results, measured and not adopted: DESIGN.md section 4); tools and opt-in tests only
+    case 27: case 33:                                                                  // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger), else as 24
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
+        if (px_ok(g)) return variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s);
+      }
+      if constexpr (EPI == HM_EPI_RESID_F32) {
+        if (off32_ok(g) && rin_ok(g)) return launch_rin<T>(g, s);
+      }
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_RESID_F32) {
+        if (off32_ok(g)) return launch_rs<T, EPI>(g, s);
+      }
+      return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
     case 1: return launch_cfg<T, EPI, 4, 2, 4, 4, 3, false>(g, s, "hm_gemm");   // 256x128, 8 waves, 3 stages (144 KB)
     case 2: return launch_cfg<T, EPI, 2, 4, 8, 4, 2, false>(g, s, "hm_gemm");   // 256x256, 8 waves, 2 stages (128 KB)
     case 3: return launch_cfg<T, EPI, 4, 2, 4, 4, 2, false>(g, s, "hm_gemm");   // 256x128, 8 waves, 2 stages (96 KB)
@@ -2029,7 +2380,7 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 28 && v <= 32)) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 33)) return true;
 #endif
   return false;
 }

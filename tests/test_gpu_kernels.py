@@ -93,7 +93,7 @@ def test_gemm_set_variant_accepts_shipped_tiles_only():
     """The experimental tiles (1-9, 11, 12, 21-23, 25, 28, 29) and the wrong-result ablations live in libhamer_hip_abl.so
     (python -m hamer_yolo_amd.build --ablations); the product refuses them instead of silently running something else."""
     lib = L.load()
-    for v in (1, 8, 9, 12, 14, 17, 21, 23, 25, 28, 29, 30, 31, 99):
+    for v in (1, 8, 9, 12, 14, 17, 21, 23, 25, 27, 28, 29, 30, 31, 33, 99):
         assert lib.hm_gemm_set_variant(v) != 0, v
     for v in (0, 10, 24, 26, -1):
         assert lib.hm_gemm_set_variant(v) == 0, v
@@ -143,7 +143,19 @@ def test_gemm_deep_prefetch_variant_exact(dt):
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gemm_persistent_kernel_exact(dt):
-    """gemm_px_kernel (variant 26: one workgroup per CU walks its tiles, the LDS-DMA pipeline runs across tile boundaries,
+    _persistent_kernel_exact(dt, 26)
+
+
+@pytest.mark.parametrize("pv", [27, 33])
+def test_gemm_pipelined_persistent_experiment_exact(pv, experiments_lib):
+    _persistent_kernel_exact(torch.float16, pv)
+
+
+def _persistent_kernel_exact(dt, pv):
+    """Variants 27 / 33 = gemm_pp_kernel, round 4, experiments library only: the same persistent walk with a software-pipelined K loop (fragment reads issued from
+    asm five groups ahead and waited for by count, the step's barrier at group 12, W two steps ahead) -- same K order, so the same
+    bytes as variant 26 / 24 on random data too.
+    gemm_px_kernel (variant 26: one workgroup per CU walks its tiles, the LDS-DMA pipeline runs across tile boundaries,
     hand-counted vmcnt over copies AND the epilogue's stores) on exact-integer data: bit-exact against torch for 2 and many
     K-steps, with and without bias, tile counts below / equal to / far above the CU count (1..6 tiles per workgroup, uneven
     shares), repeated launches as a race screen; the GELU epilogue bit-equal to the one-tile kernel's (variant 24)."""
@@ -155,7 +167,7 @@ def test_gemm_persistent_kernel_exact(dt):
             bias = (torch.arange(N) % 9 - 4).float()
             xd, wd, bd = x.to(DEV, dt), w.to(DEV, dt), bias.to(DEV)
             ref = (xd.float() @ wd.float().t()).cpu()                     # exact in fp32: small integers
-            L.check(lib.hm_gemm_set_variant(26))
+            L.check(lib.hm_gemm_set_variant(pv))
             for rep in range(3):
                 o = ops.gemm(xd, wd, bd, L.HM_EPI_STORE)
                 assert torch.equal(o.float().cpu(), (ref + bias).to(dt).float()), (M, N, K, rep)
@@ -174,7 +186,7 @@ def test_gemm_persistent_kernel_exact(dt):
             s24 = ops.gemm(xr, wr, bd, L.HM_EPI_STORE)
             assert torch.equal(g26[0], g24) and torch.equal(g26[1], g24) and torch.equal(s26, s24), (M, N, K)
         # shapes the persistent kernel does not take (ragged M / N, one K-step) fall back to the one-tile kernels
-        L.check(lib.hm_gemm_set_variant(26))
+        L.check(lib.hm_gemm_set_variant(pv))
         for (M, N, K) in ((300, 260, 64), (2048, 2048, 64), (1000, 1284, 192)):
             x = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
             w = ((torch.arange(N * K).reshape(N, K) * 5 + torch.arange(N)[:, None]) % 5 - 2).float()

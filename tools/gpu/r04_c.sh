@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4: copy stagger between the wave halves of the pipelined persistent GEMM (variant 33)
+set -o pipefail
+export TMPDIR=/tmp
+O=gpurun_out/r04c; mkdir -p $O
+timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "persistent_kernel_exact and 33" > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
+tail -3 $O/t.log
+VARIANTS=26,27,33 ROUNDS=6 REPS=5 EPI_STORE=1 timeout -k 10 300 python3 tools/bench_gemm_ab.py > $O/ab_store.log 2>&1 || { tail -20 $O/ab_store.log; exit 1; }
+tail -17 $O/ab_store.log
