@@ -35,6 +35,7 @@ struct KArgs {                                    // kernel-side view of either 
   const unsigned char* xs; const float* wscale; unsigned char* out_scales;   // hm_gemm_fp8
   const void* resid16; int ldr16;                 // HM_EPI_ADD_RELU: 16-bit residual (conv)
   int ksplit;                                     // HM_EPI_F32 only: K is cut into ksplit ranges, one workgroup and one [M][ldc] slab of C each
+  int kser;                                       // KSER kernels: the same ranges summed one after the other by ONE workgroup (0 / 1: one range)
   // convolution geometry (CONV only)
   const void* zeros;
   int H, Wd, Hout, Wout, ksz, stride, pad, cin_log2, taps;
@@ -371,7 +372,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
 // the groups kg > 0 hand their accumulators to group 0 through LDS (added in the order kg = 1, 2, ..: deterministic).
 // KDUAL (WK = 1): the SAME summation order in one group of waves -- even K tiles into one accumulator set, odd ones into a
 // second, added at the end -- so that a layer may run on either form, by launch size, with bit-identical results.
-template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0, int WK = 1, bool KDUAL = false>
+template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0, int WK = 1, bool KDUAL = false, bool KSER = false>
 __global__ __launch_bounds__(64 * WM * WN * WK, WK > 1 ? 1 : 2) void gemm_tn_kernel(const KArgs g) {
   constexpr int NWG = WM * WN;                        // waves of one K group
   constexpr int NW = NWG * WK;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, WK > 1 ? 1 : 2) void gemm_tn_ker
   static_assert(BM % (NWG * RPI) == 0 && BN % (NWG * RPI) == 0, "tile rows must split into whole DMA pieces per wave");
   static_assert(WK == 1 || (CONV && SCHED == 0), "K groups: written for the convolution flavour");
   static_assert(!KDUAL || (WK == 1 && CONV && SCHED == 0), "the two-accumulator form is the one-group twin of WK = 2");
+  static_assert(!KSER || (WK == 1 && CONV && SCHED == 0 && EPI != HM_EPI_F32), "serial K ranges: the one-workgroup twin of split-K");
   constexpr int XTILE_BYTES = BM * BK * 2, WTILE_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = XTILE_BYTES + WTILE_BYTES;
   constexpr int LOADS = XI + WI;
@@ -561,7 +563,54 @@ __global__ __launch_bounds__(64 * WM * WN * WK, WK > 1 ? 1 : 2) void gemm_tn_ker
     rd = rd + 1 == STAGES ? 0 : rd + 1;
     wrb = wrb + 1 == STAGES ? 0 : wrb + 1;
   };
-  if constexpr (KDUAL) {                               // (host: nk even)
+  if constexpr (KSER) {
+    // Round 4: the split-K summation order WITHOUT the split.  Split-K (conv_split_rule: a rule on one image, so that a frame
+    // gets the same bytes alone and in a batch) gives every K range its own workgroup, an fp32 slab in HBM and a reduce kernel
+    // that adds the slabs in order -- right for a few frames, where a layer has too few tiles to fill the chip, and 15-30 %
+    // slower than no split at all once a pass carries 48 frames.  Here ONE workgroup walks the ranges one after the other with the
+    // ring running through: a range accumulates from zero exactly as its split-K workgroup does (two sets for even / odd K tiles
+    // under KDUAL, joined as that kernel joins them), and the running total takes the ranges in the reduce kernel's order
+    // ((0 + p0) + p1) + ...; the ordinary epilogue then rounds acc + bias -> activation as that kernel does.  Same bytes, no
+    // slabs, no second launch.
+    f32x4_t tot[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) tot[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nkr = nk / g.kser;                        // (host: divisible, and even under KDUAL)
+    int kt = 0;
+    for (int r = 0; r < g.kser; ++r) {
+      const int end = kt + nkr;
+      if constexpr (KDUAL) {
+        f32x4_t acc2[NI][MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+          for (int b = 0; b < MI; ++b) acc2[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (; kt < end; kt += 2) {
+          kstep(kt, acc);
+          kstep(kt + 1, acc2);
+        }
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+          for (int b = 0; b < MI; ++b) acc[a][b] += acc2[a][b];
+      } else {
+        for (; kt < end; ++kt) kstep(kt, acc);
+      }
+#pragma unroll
+      for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+          tot[a][b] += acc[a][b];
+          acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = tot[a][b];
+  } else if constexpr (KDUAL) {                        // (host: nk even)
     f32x4_t acc2[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -2265,14 +2314,15 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restri
   fin[m] = float2{mean, 1.0f / sqrtf(fmaxf(b * invD - mean * mean, 0.f) + eps)};
 }
 
-template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0, int WK = 1, bool KDUAL = false>
+template <class T, int EPI, int WM, int WN, int MI, int NI, int STAGES, bool CONV, int BK = 64, int SCHED = 0, int WK = 1, bool KDUAL = false, bool KSER = false>
 int launch_cfg(const KArgs& g, hipStream_t s, const char* what) {
   constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
   constexpr int RING = WK * STAGES * (BM + BN) * BK * 2, EPIB = WM * WN * epi_stage_bytes(MI, NI, WM * WN > 8 ? 8 : 16);
   constexpr int LDS = (RING > EPIB ? RING : EPIB) + BM * 8 + BN * 8;     // + row statistics + column vectors
   static_assert(LDS <= 160 * 1024, "fits the CU's LDS");
-  if ((WK > 1 || KDUAL) && (g.K / BK / (EPI == HM_EPI_F32 ? g.ksplit : 1)) % 2 != 0) return hm_set_error(HM_ERR_ARG, "gemm: K tiles do not split over the K groups");
-  auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED, WK, KDUAL>;
+  if ((WK > 1 || KDUAL) && (g.K / BK / (EPI == HM_EPI_F32 ? g.ksplit : (KSER ? g.kser : 1))) % 2 != 0) return hm_set_error(HM_ERR_ARG, "gemm: K tiles do not split over the K groups");
+  if (KSER && (g.kser < 1 || (g.K / BK) % g.kser != 0)) return hm_set_error(HM_ERR_ARG, "gemm: K tiles do not split over the serial ranges");
+  auto kern = gemm_tn_kernel<T, EPI, WM, WN, MI, NI, STAGES, CONV, BK, SCHED, WK, KDUAL, KSER>;
   static HmLdsOnce lds_once;
   if (const int rc = lds_once.ensure((const void*)kern, LDS, "gemm: cannot raise the dynamic LDS limit")) return rc;
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == HM_EPI_F32 ? g.ksplit : 1);
@@ -3380,7 +3430,9 @@ int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
 enum { CT_128x128 = 0, CT_128x64 = 1, CT_128x32 = 2, CT_256x128 = 3, CT_256x256 = 4, CT_256x64 = 5,
        CT_128x32_D = 6, CT_128x64_D = 7, CT_128x128_D = 8,                      // _D: deep ring (4 / 4 / 3 stages) for lone workgroups
        CT_128x32_K2 = 9, CT_128x64_K2 = 10, CT_128x128_K2 = 11,                 // _K2: two K groups of four waves (3 / 3 / 2 stages each)
-       CT_128x32_P2 = 12, CT_128x64_P2 = 13, CT_128x128_P2 = 14, CT_COUNT = 15 }; // _P2: one group, two accumulator sets -- the K2 order
+       CT_128x32_P2 = 12, CT_128x64_P2 = 13, CT_128x128_P2 = 14, CT_COUNT = 15,    // _P2: one group, two accumulator sets -- the K2 order
+       // (not forceable, chosen by launch_conv only) _S: the split-K ranges summed serially by one workgroup; _SP2: with the K2 order inside a range
+       CT_128x32_S = 15, CT_128x64_S = 16, CT_128x128_S = 17, CT_128x32_SP2 = 18, CT_128x64_SP2 = 19, CT_128x128_SP2 = 20 };
 constexpr int ct_bm(int t) { return (t >= CT_256x128 && t <= CT_256x64) ? 256 : 128; }
 constexpr int ct_bn(int t) {
   return (t == CT_128x128 || t == CT_256x128 || t == CT_128x128_D || t == CT_128x128_K2 || t == CT_128x128_P2) ? 128
@@ -3448,6 +3500,20 @@ int launch_conv_tile(const KArgs& g, int t, hipStream_t s) {
     case CT_128x32_P2: return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
     case CT_128x64_P2: return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
     case CT_128x128_P2: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
+    default: break;
+  }
+  if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_SILU || EPI == HM_EPI_RELU) {
+    switch (t) {
+      case CT_128x32_S: return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true, 64, 0, 1, false, true>(g, s, "hm_conv2d_nhwc");
+      case CT_128x64_S: return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true, 64, 0, 1, false, true>(g, s, "hm_conv2d_nhwc");
+      case CT_128x128_S: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true, 64, 0, 1, false, true>(g, s, "hm_conv2d_nhwc");
+      case CT_128x32_SP2: return launch_cfg<T, EPI, 2, 2, 4, 1, 2, true, 64, 0, 1, true, true>(g, s, "hm_conv2d_nhwc");
+      case CT_128x64_SP2: return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true, 64, 0, 1, true, true>(g, s, "hm_conv2d_nhwc");
+      case CT_128x128_SP2: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true, 64, 0, 1, true, true>(g, s, "hm_conv2d_nhwc");
+      default: break;
+    }
+  }
+  switch (t) {
     default: return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unknown tile");
   }
 }
@@ -3512,7 +3578,24 @@ int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStr
   int ks = (ws && g.bias && act_ok && ((((uintptr_t)ws) | ((uintptr_t)g.C)) & 15) == 0) ? conv_split_rule(g) : 1;   // (the reduce kernel stores 16 bytes per lane)
   if (ks > 1 && (size_t)ks * g.M * g.N * 4 > ws_bytes)
     return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: splitk_ws too small (hm_conv_splitk_bytes gives the size; the split must not depend on what fits)");
-  const int t = pick_conv_tile(g, ks, conv_kgroups(g, ks));
+  const int kgr = conv_kgroups(g, ks);
+  // Many tiles already (a pass of many frames): the split-K ranges one after the other in ONE workgroup -- the same bytes as the
+  // split (gemm_tn_kernel<..., KSER>), without slabs and without the reduce launch.  HM_OPT_CONV_SPLITK = 2..: tuning runs force
+  // the parallel split.
+  if (ks > 1 && hm_option(HM_OPT_CONV_SPLITK) == 0) {
+    int ts = g.N > 64 ? CT_128x128 : (g.N > 32 ? CT_128x64 : CT_128x32);
+    if (conv_tiles(g, ts) >= 256) {
+      g.kser = ks;
+      const int t_ser = kgr == 2 ? (ts == CT_128x128 ? CT_128x128_SP2 : (ts == CT_128x64 ? CT_128x64_SP2 : CT_128x32_SP2))
+                                 : (ts == CT_128x128 ? CT_128x128_S : (ts == CT_128x64 ? CT_128x64_S : CT_128x32_S));
+      switch (epilogue) {
+        case HM_EPI_STORE: return launch_conv_tile<T, HM_EPI_STORE>(g, t_ser, s);
+        case HM_EPI_SILU: return launch_conv_tile<T, HM_EPI_SILU>(g, t_ser, s);
+        default: return launch_conv_tile<T, HM_EPI_RELU>(g, t_ser, s);
+      }
+    }
+  }
+  const int t = pick_conv_tile(g, ks, kgr);
   if (ks > 1) {
     void* y = g.C; const int ldy = g.ldc; const float* bias = g.bias;
     g.C = ws; g.ldc = g.N; g.bias = nullptr; g.ksplit = ks;

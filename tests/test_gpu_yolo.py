@@ -135,6 +135,42 @@ def test_conv_k_groups_exact_and_close(tile):
     assert (base - ref).abs().max() < 2e-3 and (plain - ref).abs().max() < 2e-3 and (base - plain).abs().max() < 2e-3
 
 
+@pytest.mark.parametrize("Ci,Co,k,s,H,W,nb", [(1024, 512, 1, 1, 12, 20, 40),     # 1x1, K = 1024 -> 2 ranges (one chain each), 128 x 128 tile
+                                              (256, 256, 3, 1, 12, 20, 72),      # 3x3, K = 2304 -> 4 ranges of 9 tiles: one chain each (odd count)
+                                              (512, 264, 3, 1, 12, 20, 48),      # K = 4608 -> 4 ranges of 18 tiles: even / odd sets inside a range; ragged N
+                                              (256, 128, 3, 1, 24, 40, 36),      # 24 x 40 map, K = 2304 -> 2 ranges of 18: two sets, 128 x 128 tile (3 accumulator sets)
+                                              (512, 64, 3, 2, 24, 40, 140)])     # stride 2 onto 12 x 20, narrow layer: 128 x 64 tile
+def test_conv_serial_k_ranges_give_the_split_k_bytes(Ci, Co, k, s, H, W, nb):
+    """Round 4: split-K is a rule on ONE image (a frame must get the same bytes alone and in a batch), but its slabs and reduce
+    launch cost 15-30 % once a detector pass carries 48 frames.  From 256 tiles on, launch_conv hands the layer to
+    gemm_tn_kernel<..., KSER>: one workgroup sums the same K ranges one after the other -- each from zero, in the split kernel's
+    order inside a range, the running total in the reduce kernel's order.  The bytes must equal (a) the parallel split forced on
+    the same batch (HM_OPT_CONV_SPLITK = the rule's own count), (b) what a lone image gets (which takes the parallel split), on
+    random data, with bias and SiLU; exact-integer data must come back exact."""
+    lib = L.load()
+    x = synth.uniform("sx", (nb, Ci, H, W), 1.0, seed=Ci + nb).half().float()
+    w = synth.uniform("sw", (Co, Ci, k, k), (3.0 / (Ci * k * k)) ** 0.5, seed=Co).half().float()
+    b = synth.uniform("sb", (Co,), 0.3, seed=k)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    probe = L.ConvArgs(1, 1, 1, 1, 1, nb, H, W, Ci, Co, k, s, Ci, Co, (k * k * Ci + 63) // 64 * 64, 1, 0, L.HM_DTYPE_F16)
+    need = lib.hm_conv_splitk_bytes(C.byref(probe))
+    ranges = need // (nb * Ho * Wo * Co * 4)
+    assert need > 0 and ranges in (2, 4), (need, ranges)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    auto = _conv_gpu(x, w, b, k, s, act=True, dt=torch.float16, y_extra=8, splitk_ws=ws)            # many tiles: the serial route
+    with L.option(L.HM_OPT_CONV_SPLITK, ranges):
+        par = _conv_gpu(x, w, b, k, s, act=True, dt=torch.float16, y_extra=8, splitk_ws=ws)         # the parallel split, forced
+    one = _conv_gpu(x[5:6], w, b, k, s, act=True, dt=torch.float16, y_extra=8, splitk_ws=ws)         # a lone image: parallel split
+    assert torch.equal(auto, par) and torch.equal(auto[5:6], one)
+    ref = F.silu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=k // 2)).float()
+    assert (auto - ref).abs().max() < 3e-3
+    xi = (torch.arange(nb * Ci * H * W).reshape(nb, Ci, H, W) % 5 - 2).float()
+    wi = ((torch.arange(Co * Ci * k * k).reshape(Co, Ci, k, k) * 7 + torch.arange(Co)[:, None, None, None]) % 3 - 1).float()
+    bi = (torch.arange(Co) % 7 - 3).float()
+    yi = _conv_gpu(xi, wi, bi, k, s, act=False, dt=torch.float16, splitk_ws=ws)
+    assert torch.equal(yi, F.conv2d(xi, wi, bi, stride=s, padding=k // 2).half().float())
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("Ci,Co,s,H,W", [(3, 32, 1, 20, 72), (3, 32, 1, 9, 150), (3, 32, 1, 33, 64), (3, 32, 1, 5, 640)])
 def test_conv_direct_stem_kernel_equals_the_implicit_gemm(Ci, Co, s, H, W, dt):
