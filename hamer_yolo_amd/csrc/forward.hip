@@ -112,11 +112,11 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
   // deferred LayerNorm (hm_gemm HM_EPI_RESID_LN / HM_EPI_LN_*): `ln` = gamma of the next LayerNorm for a GEMM that
   // writes x, or the folded column sums for a GEMM that reads LN(x); `h` then holds x * gamma instead of LN(x)
   auto gemm = [&](const void* X, int ldx, const void* W, int K, int N, void* C, int ldc, const float* bias, int epi,
-                  const float* resid, int ldr, int rmod, const float* ln = nullptr) {
+                  const float* resid, int ldr, int rmod, const float* ln = nullptr, float out_scale = 0.f) {
     hm_gemm_args g{};
     g.X = X; g.W = W; g.C = C; g.bias = bias; g.resid = resid;
     g.M = M; g.N = N; g.K = K; g.ldx = ldx; g.ldw = K; g.ldc = ldc; g.ldr = ldr; g.resid_mod = rmod;
-    g.epilogue = epi; g.dtype = dt;
+    g.epilogue = epi; g.dtype = dt; g.out_scale = out_scale;
     if (epi == HM_EPI_RESID_LN) { g.ln_gamma = ln; g.ln_xg = h; g.ln_stats = stats; }
     if (epi == HM_EPI_LN_STORE || epi == HM_EPI_LN_GELU) { g.ln_colsum = ln; g.ln_stats = rowstats; }
     HM_TRY(hm_gemm(&g, stream));
@@ -159,6 +159,16 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
     const hm_vit_block& b = w->blocks[i];
     fold = b.qkv_colsum && b.qkv_bias_ln && b.fc1_colsum && b.fc1_bias_ln;
   }
+
+  // range probe (load-time calibration, hm_hamer_weights.range_stats): slot layout in include/hamer_hip.h
+  float* rs = w->range_stats;
+  if (rs && (fp8 || fold || w->tome_r)) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: range_stats is for the dense 16-bit path");
+  auto probe = [&](const void* p, int ld, int rows, int col0, int ncols, int slot) {
+    return rs ? hm_absmax16(p, ld, rows, col0, ncols, dt, rs + slot, stream) : HM_OK;
+  };
+  for (int i = 0; i < w->depth; ++i)
+    if ((w->blocks[i].attn_scale_mul != 0.f && w->blocks[i].attn_scale_mul != 1.f) || (w->blocks[i].gelu_out_scale != 0.f && w->blocks[i].gelu_out_scale != 1.f))
+      if (fp8 || fold || w->tome_r) return hm_set_error(HM_ERR_ARG, "hm_hamer_forward: the range prescale exists on the dense 16-bit path only");
 
   // ---- ViT backbone (vit.py:320-339)
   HM_TRY(hm_patch_im2col(img, ws + L.patches, B, w->img_h, w->img_w_full, w->win_x0, w->win_w, w->patch, w->pad, dt, stream));
@@ -257,14 +267,21 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
       else HM_TRY(gemm(mlp, w->mlp_dim, b.fc2_w, w->mlp_dim, D, x, D, b.fc2_b, HM_EPI_RESID_F32, x, D, 0));   // last_norm stays a kernel
     } else {
       // the LayerNorm that follows each residual GEMM is issued with it: LN1 of block i+1 (or last_norm) after fc2
-      if (i == 0) HM_TRY(hm_layernorm(x, b.ln1_g, b.ln1_b, h, dt, M, D, w->vit_eps, stream));
+      if (i == 0) {
+        HM_TRY(hm_layernorm(x, b.ln1_g, b.ln1_b, h, dt, M, D, w->vit_eps, stream));
+        HM_TRY(probe(h, D, M, 0, D, 0));
+      }
       HM_TRY(gemm(h, D, b.qkv_w, D, 3 * D, qkv, 3 * D, b.qkv_b, HM_EPI_STORE, nullptr, 0, 0));
-      HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, scale, dt, stream));
+      for (int c = 0; c < 3; ++c) HM_TRY(probe(qkv, 3 * D, M, c * D, D, 6 * i + 1 + c));
+      HM_TRY(hm_vit_attention(qkv, att, B, tokens, w->heads, D / w->heads, b.attn_scale_mul != 0.f ? scale * b.attn_scale_mul : scale, dt, stream));
       HM_TRY(resid_gemm_ln(att, D, b.proj_w, b.proj_b, L.ksplit_proj, b.ln2_g, b.ln2_b, h));
-      HM_TRY(gemm(h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0));
+      HM_TRY(probe(h, D, M, 0, D, 6 * i + 4));
+      HM_TRY(gemm(h, D, b.fc1_w, D, w->mlp_dim, mlp, w->mlp_dim, b.fc1_b, HM_EPI_GELU, nullptr, 0, 0, nullptr, b.gelu_out_scale));
+      HM_TRY(probe(mlp, w->mlp_dim, M, 0, w->mlp_dim, 6 * i + 5));
       const bool last = i + 1 == w->depth;
       HM_TRY(resid_gemm_ln(mlp, w->mlp_dim, b.fc2_w, b.fc2_b, L.ksplit_fc2, last ? w->last_g : w->blocks[i + 1].ln1_g,
                            last ? w->last_b : w->blocks[i + 1].ln1_b, last ? tok : h));
+      HM_TRY(probe(last ? tok : h, D, M, 0, D, 6 * (i + 1)));       // LN1 of block i + 1, or last_norm (slot 6 * depth)
     }
   }
   if (fold || fp8) HM_TRY(hm_layernorm(x, w->last_g, w->last_b, tok, dt, M, D, w->vit_eps, stream));
@@ -277,6 +294,10 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
     g.X = tok; g.W = w->kv_w; g.C = kv; g.M = B * ctx_tokens; g.N = ldkv; g.K = D; g.ldx = D; g.ldw = D; g.ldc = ldkv;
     g.epilogue = HM_EPI_STORE; g.dtype = dt;
     HM_TRY(hm_gemm(&g, stream));
+    for (int i = 0; i < w->dec_depth; ++i) {
+      HM_TRY(probe(kv, ldkv, B * ctx_tokens, i * 2 * inner, inner, 6 * w->depth + 1 + 2 * i));
+      HM_TRY(probe(kv, ldkv, B * ctx_tokens, i * 2 * inner + inner, inner, 6 * w->depth + 2 + 2 * i));
+    }
   }
   float *xd = (float*)(ws + L.xd), *hd = (float*)(ws + L.hd), *t1 = (float*)(ws + L.t1), *t2 = (float*)(ws + L.t2);
   HM_TRY(hm_broadcast_rows(w->token0, xd, B, dim, stream));
@@ -297,7 +318,7 @@ extern "C" int hm_hamer_forward(const hm_hamer_weights* w, const float* img, int
     HM_TRY(hm_layernorm(xd, l.ln1_g, l.ln1_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));
     HM_TRY(hm_linear_f32(hd, dim, l.ca_q_w, dim, nullptr, nullptr, 0, t1, inner, B, inner, dim, 0, stream));
     HM_TRY(hm_cross_attention(t1, kv, ldkv, i * 2 * inner, i * 2 * inner + inner, t2, B, ctx_tokens, w->dec_heads,
-                              w->dec_dim_head, dscale, dt, stream));
+                              w->dec_dim_head, l.ca_scale_mul != 0.f ? dscale * l.ca_scale_mul : dscale, dt, stream));
     HM_TRY(hm_linear_f32(t2, inner, l.ca_out_w, inner, l.ca_out_b, xd, dim, xd, dim, B, dim, inner, 0, stream));
     // feed-forward (pose_transformer.py:40-52)
     HM_TRY(hm_layernorm(xd, l.ln2_g, l.ln2_b, hd, HM_OUT_F32, B, dim, w->dec_eps, stream));

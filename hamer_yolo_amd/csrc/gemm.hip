@@ -35,6 +35,7 @@ struct KArgs {                                    // kernel-side view of either 
   const unsigned char* xs; const float* wscale; unsigned char* out_scales;   // hm_gemm_fp8
   const void* resid16; int ldr16;                 // HM_EPI_ADD_RELU: 16-bit residual (conv)
   int ksplit;                                     // HM_EPI_F32 only: K is cut into ksplit ranges, one workgroup and one [M][ldc] slab of C each
+  float out_scale;                                // HM_EPI_GELU (16-bit out): C = gelu(acc + bias) * out_scale (a power of two; 1 = the plain epilogue)
   int kser;                                       // KSER kernels: the same ranges summed one after the other by ONE workgroup (0 / 1: one range)
   // convolution geometry (CONV only)
   const void* zeros;
@@ -260,6 +261,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
           float a = v0[q], b = v1[q];
           if (ACT_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0]; b = gq[1]; }
           else if (EPI == HM_EPI_SILU) { a = silu(a); b = silu(b); }
+          if constexpr (EPI == HM_EPI_GELU) { a *= g.out_scale; b *= g.out_scale; }      // (x 1.0f is exact: the same bytes without a prescale)
           o[q] = (elem)a; o[4 + q] = (elem)b;
         }
         if constexpr (RELU) {                        // (+ identity), ReLU; host guarantees N % 8 == 0 and 16-byte rows
@@ -338,7 +340,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         }
         if (EPI == HM_EPI_GELU) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]);
+          for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]) * g.out_scale;
         } else if (EPI == HM_EPI_SILU) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
@@ -1411,7 +1413,7 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
               // (pairs as the staged epilogue forms them: values q and 4 + q of a lane's 8 columns -- there columns c, c + 4;
               //  gelu_fast2 evaluates its two values independently, so the pairing does not change a result)
               const f32x2_t g0 = gelu_fast2(f32x2_t{v0, v1}), g1 = gelu_fast2(f32x2_t{v2, v3});
-              v0 = g0[0]; v1 = g0[1]; v2 = g1[0]; v3 = g1[1];
+              v0 = g0[0] * g.out_scale; v1 = g0[1] * g.out_scale; v2 = g1[0] * g.out_scale; v3 = g1[1] * g.out_scale;
             }
             typename T::vec4 o;
             o[0] = (elem)v0; o[1] = (elem)v1; o[2] = (elem)v2; o[3] = (elem)v3;
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float a = __fadd_rn(v0[q], b0[q]), b = __fadd_rn(v1[q], b1[q]);           // as the one-tile kernels round
-            if constexpr (EPI == HM_EPI_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0]; b = gq[1]; }
+            if constexpr (EPI == HM_EPI_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0] * g.out_scale; b = gq[1] * g.out_scale; }
             o[q] = (elem)a; o[4 + q] = (elem)b;
           }
           *(vec8*)((elem*)g.C + (size_t)(mb + half * 32 + row) * g.ldc + nb + cg * 32 + 8 * j) = o;
@@ -1728,7 +1730,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const KArgs g) {
             float v0 = __fadd_rn(a[0], bb[0]), v1 = __fadd_rn(a[1], bb[1]), v2 = __fadd_rn(a[2], bb[2]), v3 = __fadd_rn(a[3], bb[3]);
             if constexpr (EPI == HM_EPI_GELU) {
               const f32x2_t g0 = gelu_fast2(f32x2_t{v0, v1}), g1 = gelu_fast2(f32x2_t{v2, v3});
-              v0 = g0[0]; v1 = g0[1]; v2 = g1[0]; v3 = g1[1];
+              v0 = g0[0] * g.out_scale; v1 = g0[1] * g.out_scale; v2 = g1[0] * g.out_scale; v3 = g1[1] * g.out_scale;
             }
             typename T::vec4 o;
             o[0] = (elem)v0; o[1] = (elem)v1; o[2] = (elem)v2; o[3] = (elem)v3;
@@ -1761,7 +1763,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const KArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float a = __fadd_rn(v0[q], b0[q]), b = __fadd_rn(v1[q], b1[q]);
-              if constexpr (EPI == HM_EPI_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0]; b = gq[1]; }
+              if constexpr (EPI == HM_EPI_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0] * g.out_scale; b = gq[1] * g.out_scale; }
               o[q] = (elem)a; o[4 + q] = (elem)b;
             }
             *(vec8*)((elem*)g.C + (size_t)(mb + half * 32 + row) * g.ldc + nb + cg * 32 + 8 * j) = o;
@@ -3665,6 +3667,8 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
   k.M = g.M; k.N = g.N; k.K = g.K; k.ldx = g.ldx; k.ldw = g.ldw; k.ldc = g.ldc; k.ldr = g.ldr; k.resid_mod = g.resid_mod;
   k.group_m = g_group_m;
   k.ksplit = 1;
+  k.out_scale = g.out_scale != 0.0f ? g.out_scale : 1.0f;
+  if (k.out_scale != 1.0f && g.epilogue != HM_EPI_GELU) return hm_set_error(HM_ERR_ARG, "hm_gemm: out_scale applies to HM_EPI_GELU only");
   if (g.k_split > 1) {
     if (g.epilogue != HM_EPI_F32 || g.bias || g.K % (BK_DEFAULT * g.k_split) != 0)
       return hm_set_error(HM_ERR_ARG, "hm_gemm: k_split needs HM_EPI_F32, no bias and K % (64 * k_split) == 0");

@@ -308,3 +308,33 @@ extern "C" int hm_broadcast_rows(const float* vec, float* out, int B, int D, voi
                      out, B, D);
   return hm_check_launch("hm_broadcast_rows");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Range probe (load-time calibration of the fp16 prescale, hm_hamer_weights.range_stats): max |x| of a column range of a 16-bit
+// matrix.  Non-negative floats order like their bit patterns, so one integer atomic max per workgroup folds the result; an
+// infinity or NaN in the data (bit pattern above every finite one) reads back as non-finite, which is what the caller tests.
+template <class E>
+__global__ __launch_bounds__(256) void absmax16_kernel(const E* __restrict__ x, int ld, int M, int col0, int ncols, float* slot) {
+  const size_t total = (size_t)M * ncols;
+  float m = 0.f;
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / ncols, c = i - r * ncols;
+    const float v = fabsf((float)x[r * ld + col0 + c]);
+    bad |= !(v <= 3.0e38f);
+    m = fmaxf(m, v);
+  }
+  if (bad) m = __builtin_inff();
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)slot, __float_as_uint(m));
+}
+
+extern "C" int hm_absmax16(const void* x, int ld, int M, int col0, int ncols, int dtype, float* slot, void* stream_) {
+  if (!x || !slot || M <= 0 || ncols <= 0 || ld < col0 + ncols || col0 < 0) return hm_set_error(HM_ERR_ARG, "hm_absmax16: bad arguments");
+  const size_t total = (size_t)M * ncols;
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  if (dtype == HM_DTYPE_BF16) hipLaunchKernelGGL((absmax16_kernel<__bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const __bf16*)x, ld, M, col0, ncols, slot);
+  else if (dtype == HM_DTYPE_F16) hipLaunchKernelGGL((absmax16_kernel<_Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const _Float16*)x, ld, M, col0, ncols, slot);
+  else return hm_set_error(HM_ERR_ARG, "hm_absmax16: dtype must be HM_DTYPE_BF16 or HM_DTYPE_F16");
+  return hm_check_launch("hm_absmax16");
+}

@@ -40,6 +40,28 @@ def parse_tome_r(num_layers: int, r):
     return [int(lo + step * i) for i in range(num_layers)]
 
 
+RANGE_LIMIT = 4096.0      # prescale target: calibrated magnitudes end up at or below this, 16x under fp16's 65504
+
+
+def prescale_from_ranges(ranges, depth: int, dec_depth: int, limit: float = RANGE_LIMIT) -> Dict:
+    """Power-of-two exponents per 16-bit activation class from the magnitudes hm_hamer_forward recorded (range_stats layout:
+    per block [LN1 out, q, k, v, LN2 out, GELU out], last_norm out, per decoder layer [k, v]): a = max(0, ceil(log2(m / limit))),
+    i.e. the class is stored as value * 2^-a.  Non-finite magnitudes (the probe itself overflowed) are an error."""
+    import math
+    r = [float(v) for v in ranges]
+    if len(r) != 6 * depth + 1 + 2 * dec_depth or not all(math.isfinite(v) for v in r):
+        raise L.HipLibraryError("prescale_from_ranges: bad or non-finite range statistics (measure them with bf16 operands)")
+    ex = [max(0, math.ceil(math.log2(v / limit))) if v > limit else 0 for v in r]
+    keys = ("ln1", "q", "k", "v", "ln2", "gelu")
+    return {"blocks": [dict(zip(keys, ex[6 * i:6 * i + 6])) for i in range(depth)], "last": ex[6 * depth],
+            "dec": [(ex[6 * depth + 1 + 2 * i], ex[6 * depth + 2 + 2 * i]) for i in range(dec_depth)]}
+
+
+def prescale_is_identity(pre: Optional[Dict]) -> bool:
+    return pre is None or (all(v == 0 for b in pre["blocks"] for v in b.values()) and pre["last"] == 0
+                           and all(a == 0 and b == 0 for a, b in pre["dec"]))
+
+
 class ForwardContext:
     """One batch in flight: its own HIP stream, workspace and output tensors (HamerEngine.contexts)."""
 
@@ -50,7 +72,13 @@ class ForwardContext:
 class HamerEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], mano: Dict[str, torch.Tensor],
                  cfg: Optional[HamerConfig] = None, device="cuda", dtype=torch.float16, fold_ln: Optional[bool] = None,
-                 fp8: Optional[bool] = None, token_merge=None):
+                 fp8: Optional[bool] = None, token_merge=None, prescale: Optional[Dict] = None):
+        """``prescale`` (round 4, `prescale_from_ranges`): per activation class a power of two folded into the weights at load --
+        LayerNorm gamma / beta against the columns of the matrix that reads its output, q / k / v rows of qkv against the
+        softmax scale and proj, the GELU output (an epilogue factor) against fc2, to_kv rows against the cross-attention scale
+        and its to_out -- so that every 16-bit activation of a checkpoint that overflows fp16 lands inside it while the operands
+        keep their 11 significant bits.  Exact arithmetic: powers of two commute with rounding (no value underflows on the way),
+        so the forward computes the same function.  ``want_tokens`` then returns last_norm's output times 2^-prescale['last']."""
         if not torch.cuda.is_available():
             raise L.HipLibraryError("HamerEngine needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = L.load()
@@ -100,17 +128,46 @@ class HamerEngine:
             self._keep += [q, sc]
             return L.ptr(q), L.ptr(sc)
 
+        pre = None if prescale_is_identity(prescale) else prescale
+        if pre is not None and (self.fp8 or self.fold_ln or token_merge):
+            raise L.HipLibraryError("the range prescale exists on the dense 16-bit path only (not fp8, deferred LayerNorm or token merging)")
+        self.prescale = pre
+        limit16 = 65504.0 if dtype == torch.float16 else 3.0e38
+
+        def scaled(t, e):
+            """t * 2^e in fp32 (exact), refusing a matrix that would leave the operand type's range."""
+            t = t.detach().to(self.device, torch.float32)
+            if e == 0:
+                return t
+            t = t * (2.0 ** e)
+            if float(t.abs().max()) >= limit16:
+                raise L.HipLibraryError("range prescale: a compensated weight matrix leaves the fp16 range")
+            return t
+
         D = v.embed_dim
         self.blocks = (L.VitBlock * v.depth)()
         for i in range(v.depth):
             p = f"backbone.blocks.{i}."
             b = self.blocks[i]
-            b.ln1_g, b.ln1_b = L.ptr(f32(sd[p + "norm1.weight"])), L.ptr(f32(sd[p + "norm1.bias"]))
-            b.ln2_g, b.ln2_b = L.ptr(f32(sd[p + "norm2.weight"])), L.ptr(f32(sd[p + "norm2.bias"]))
-            b.qkv_w, b.qkv_b = L.ptr(w16(sd[p + "attn.qkv.weight"])), L.ptr(f32(sd[p + "attn.qkv.bias"]))
-            b.proj_w, b.proj_b = L.ptr(w16(sd[p + "attn.proj.weight"])), L.ptr(f32(sd[p + "attn.proj.bias"]))
-            b.fc1_w, b.fc1_b = L.ptr(w16(sd[p + "mlp.fc1.weight"])), L.ptr(f32(sd[p + "mlp.fc1.bias"]))
-            b.fc2_w, b.fc2_b = L.ptr(w16(sd[p + "mlp.fc2.weight"])), L.ptr(f32(sd[p + "mlp.fc2.bias"]))
+            if pre is None:
+                b.ln1_g, b.ln1_b = L.ptr(f32(sd[p + "norm1.weight"])), L.ptr(f32(sd[p + "norm1.bias"]))
+                b.ln2_g, b.ln2_b = L.ptr(f32(sd[p + "norm2.weight"])), L.ptr(f32(sd[p + "norm2.bias"]))
+                b.qkv_w, b.qkv_b = L.ptr(w16(sd[p + "attn.qkv.weight"])), L.ptr(f32(sd[p + "attn.qkv.bias"]))
+                b.proj_w, b.proj_b = L.ptr(w16(sd[p + "attn.proj.weight"])), L.ptr(f32(sd[p + "attn.proj.bias"]))
+                b.fc1_w, b.fc1_b = L.ptr(w16(sd[p + "mlp.fc1.weight"])), L.ptr(f32(sd[p + "mlp.fc1.bias"]))
+                b.fc2_w, b.fc2_b = L.ptr(w16(sd[p + "mlp.fc2.weight"])), L.ptr(f32(sd[p + "mlp.fc2.bias"]))
+            else:
+                e = pre["blocks"][i]
+                b.ln1_g, b.ln1_b = L.ptr(f32(scaled(sd[p + "norm1.weight"], -e["ln1"]))), L.ptr(f32(scaled(sd[p + "norm1.bias"], -e["ln1"])))
+                b.ln2_g, b.ln2_b = L.ptr(f32(scaled(sd[p + "norm2.weight"], -e["ln2"]))), L.ptr(f32(scaled(sd[p + "norm2.bias"], -e["ln2"])))
+                wq, bq = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
+                b.qkv_w = L.ptr(w16(torch.cat([scaled(wq[j * D:(j + 1) * D], e["ln1"] - e[c]) for j, c in enumerate("qkv")], 0)))
+                b.qkv_b = L.ptr(f32(torch.cat([scaled(bq[j * D:(j + 1) * D], -e[c]) for j, c in enumerate("qkv")], 0)))
+                b.attn_scale_mul = 2.0 ** (e["q"] + e["k"])
+                b.proj_w, b.proj_b = L.ptr(w16(scaled(sd[p + "attn.proj.weight"], e["v"]))), L.ptr(f32(sd[p + "attn.proj.bias"]))
+                b.fc1_w, b.fc1_b = L.ptr(w16(scaled(sd[p + "mlp.fc1.weight"], e["ln2"]))), L.ptr(f32(sd[p + "mlp.fc1.bias"]))
+                b.gelu_out_scale = 2.0 ** -e["gelu"]
+                b.fc2_w, b.fc2_b = L.ptr(w16(scaled(sd[p + "mlp.fc2.weight"], e["gelu"]))), L.ptr(f32(sd[p + "mlp.fc2.bias"]))
             if self.fp8:
                 b.qkv_w8, b.qkv_ws = w8(sd[p + "attn.qkv.weight"])
                 b.fc1_w8, b.fc1_ws = w8(sd[p + "mlp.fc1.weight"])
@@ -149,10 +206,17 @@ class HamerEngine:
             l.sa_w = L.ptr(f32((sd[p + "0.fn.to_out.0.weight"].to(self.device, torch.float64)
                                 @ sd[p + "0.fn.to_qkv.weight"][2 * inner:3 * inner].to(self.device, torch.float64)).float()))
             l.ca_q_w = L.ptr(f32(sd[p + "1.fn.to_q.weight"]))
-            l.ca_out_w, l.ca_out_b = L.ptr(f32(sd[p + "1.fn.to_out.0.weight"])), L.ptr(f32(sd[p + "1.fn.to_out.0.bias"]))
+            ekk, ekv = pre["dec"][i] if pre is not None else (0, 0)
+            l.ca_out_w, l.ca_out_b = L.ptr(f32(scaled(sd[p + "1.fn.to_out.0.weight"], ekv))), L.ptr(f32(sd[p + "1.fn.to_out.0.bias"]))
+            if pre is not None:
+                l.ca_scale_mul = 2.0 ** ekk
             l.ff1_w, l.ff1_b = L.ptr(f32(sd[p + "2.fn.net.0.weight"])), L.ptr(f32(sd[p + "2.fn.net.0.bias"]))
             l.ff2_w, l.ff2_b = L.ptr(f32(sd[p + "2.fn.net.3.weight"])), L.ptr(f32(sd[p + "2.fn.net.3.bias"]))
-            kv_rows.append(sd[p + "1.fn.to_kv.weight"].to(torch.float32))
+            wkv = sd[p + "1.fn.to_kv.weight"]
+            if pre is None:
+                kv_rows.append(wkv.to(torch.float32))
+            else:             # [k rows | v rows] of this layer (pose_transformer.py:114-115 chunk(2)), against last_norm's prescale
+                kv_rows.append(torch.cat([scaled(wkv[:inner], pre["last"] - ekk), scaled(wkv[inner:], pre["last"] - ekv)], 0))
         token0 = sd[t + "to_token_embedding.bias"].to(torch.float32) + sd[t + "pos_embedding"].to(torch.float32)[0, 0]
         head_w = torch.zeros(112, d.dim, dtype=torch.float32, device=sd["mano_head.decpose.weight"].device)
         head_b = torch.zeros(112, dtype=torch.float32, device=head_w.device)
@@ -173,7 +237,8 @@ class HamerEngine:
         w.patch_b = L.ptr(f32(sd["backbone.patch_embed.proj.bias"]))
         w.pos = L.ptr(f32(pos))
         w.blocks = C.cast(self.blocks, C.POINTER(L.VitBlock))
-        w.last_g, w.last_b = L.ptr(f32(sd["backbone.last_norm.weight"])), L.ptr(f32(sd["backbone.last_norm.bias"]))
+        elast = pre["last"] if pre is not None else 0
+        w.last_g, w.last_b = L.ptr(f32(scaled(sd["backbone.last_norm.weight"], -elast))), L.ptr(f32(scaled(sd["backbone.last_norm.bias"], -elast)))
         w.dec_dim, w.dec_depth, w.dec_heads, w.dec_dim_head, w.dec_mlp = d.dim, d.depth, d.heads, d.dim_head, d.mlp_dim
         w.dec_eps = d.ln_eps
         w.token0 = L.ptr(f32(token0))
@@ -211,6 +276,22 @@ class HamerEngine:
         out = self.forward(img, want_tokens=self.tome_r is None)
         torch.cuda.synchronize(self.device)
         return all(bool(torch.isfinite(v.float()).all()) for v in out.values())
+
+    def measure_ranges(self, n: int = 4) -> torch.Tensor:
+        """Largest magnitude of every 16-bit activation class over one forward of `n` calibration crops (hm_hamer_weights.
+        range_stats; layout in include/hamer_hip.h).  Meant for an engine with bfloat16 operands, whose exponent range cannot
+        overflow: the result feeds prescale_from_ranges for the fp16 engine of the same checkpoint."""
+        from . import synth
+        v, d = self.cfg.vit, self.cfg.dec
+        stats = torch.zeros(6 * v.depth + 1 + 2 * d.depth, dtype=torch.float32, device=self.device)
+        img = synth.normalize_crops(synth.crops_u8(n, seed0=0)).to(self.device)
+        self.w.range_stats = L.ptr(stats)
+        try:
+            self.forward(img)
+            torch.cuda.synchronize(self.device)
+        finally:
+            self.w.range_stats = None
+        return stats.cpu()
 
     # ------------------------------------------------------------------ run
     def workspace(self, B: int) -> torch.Tensor:

@@ -88,13 +88,35 @@ class HAMER:
             # at load, that this checkpoint's activations fit; if not, take the wider exponent and say so
             if self.dtype == torch.float16 and self.check_fp16_range and not self._engine.calibration_is_finite():
                 import warnings
-                warnings.warn("HAMER: this checkpoint overflows fp16 GEMM operands on the calibration crops; falling back to "
-                              "bfloat16 operands (pose / shape within ~2e-3 of the fp32 reference instead of 2e-4)")
-                self.dtype = torch.bfloat16
-                self._engine = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=self.dtype,
-                                           token_merge=self.token_merge or None)
-                if not self._engine.calibration_is_finite():
+                from ...engine import prescale_from_ranges
+                # Round 4: keep the 11-bit operands.  A bf16 engine of the same checkpoint (fp32's exponent range) measures how
+                # large every 16-bit activation class gets; powers of two folded into the weights bring each class back inside
+                # fp16 (HamerEngine prescale: exact arithmetic, the same function).  bfloat16 operands -- 8 significant bits,
+                # 1.2-1.9e-3 from the fp32 reference on theta / beta -- remain the last resort (and what token merging takes).
+                self._engine = None
+                probe = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=torch.bfloat16)
+                if not probe.calibration_is_finite():
                     raise HipLibraryError("HAMER: non-finite outputs on the calibration crops with bfloat16 operands too: bad checkpoint?")
+                eng = None
+                if not self.token_merge:
+                    try:
+                        pre = prescale_from_ranges(probe.measure_ranges(), self._hc.vit.depth, self._hc.dec.depth)
+                        eng = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=torch.float16, prescale=pre)
+                        if not eng.calibration_is_finite():
+                            eng = None
+                    except HipLibraryError:
+                        eng = None
+                del probe
+                if eng is not None:
+                    warnings.warn("HAMER: this checkpoint overflows fp16 GEMM operands on the calibration crops; its activations "
+                                  "were rescaled by powers of two folded into the weights (fp16 operands kept)")
+                    self._engine = eng
+                else:
+                    warnings.warn("HAMER: this checkpoint overflows fp16 GEMM operands on the calibration crops; falling back to "
+                                  "bfloat16 operands (pose / shape within ~2e-3 of the fp32 reference instead of 2e-4)")
+                    self.dtype = torch.bfloat16
+                    self._engine = HamerEngine(self._sd, self.mano.params, self._hc, device=device, dtype=self.dtype,
+                                               token_merge=self.token_merge or None)
             self.device = device
         return self
 

@@ -30,7 +30,7 @@ EXPORTS = [
     "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
     "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes", "hm_yolo_decode_batch", "hm_letterbox_batch",
-    "hm_option_count", "hm_gemm_px_grid",
+    "hm_option_count", "hm_gemm_px_grid", "hm_absmax16",
 ]
 KIND_NAMES = ["gemm", "layernorm", "attention", "im2col", "linear_f32", "cross_attn", "mano", "crop", "conv", "other"]
 
@@ -47,7 +47,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("ldx", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
                 ("resid_mod", C.c_int), ("epilogue", C.c_int), ("dtype", C.c_int),
-                ("ln_gamma", vp), ("ln_xg", vp), ("ln_stats", vp), ("ln_colsum", vp), ("k_split", C.c_int)]
+                ("ln_gamma", vp), ("ln_xg", vp), ("ln_stats", vp), ("ln_colsum", vp), ("k_split", C.c_int), ("out_scale", C.c_float)]
 
 
 class GemmFp8Args(C.Structure):
@@ -70,12 +70,14 @@ class VitBlock(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "proj_w", "fc1_w", "fc2_w",
                                   "qkv_b", "proj_b", "fc1_b", "fc2_b",
                                   "qkv_colsum", "qkv_bias_ln", "fc1_colsum", "fc1_bias_ln",
-                                  "qkv_w8", "fc1_w8", "fc2_w8", "qkv_ws", "fc1_ws", "fc2_ws", "proj_w8", "proj_ws", "kmean_w", "kmean_b")]
+                                  "qkv_w8", "fc1_w8", "fc2_w8", "qkv_ws", "fc1_ws", "fc2_ws", "proj_w8", "proj_ws", "kmean_w", "kmean_b")] + \
+               [("attn_scale_mul", C.c_float), ("gelu_out_scale", C.c_float)]
 
 
 class DecLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "sa_v_w", "sa_w", "sa_out_w",
-                                  "sa_out_b", "ca_q_w", "ca_out_w", "ca_out_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")]
+                                  "sa_out_b", "ca_q_w", "ca_out_w", "ca_out_b", "ff1_w", "ff1_b", "ff2_w", "ff2_b")] + \
+               [("ca_scale_mul", C.c_float)]
 
 
 class HamerWeights(C.Structure):
@@ -86,7 +88,8 @@ class HamerWeights(C.Structure):
                [(n, C.c_int) for n in ("dec_dim", "dec_depth", "dec_heads", "dec_dim_head", "dec_mlp")] + \
                [("dec_eps", C.c_float), ("token0", vp), ("kv_w", vp), ("layers", C.POINTER(DecLayer)),
                 ("head_w", vp), ("head_b", vp), ("mano", ManoModel),
-                ("focal_length", C.c_float), ("image_size", C.c_float), ("dtype", C.c_int), ("tome_r", C.POINTER(C.c_int))]
+                ("focal_length", C.c_float), ("image_size", C.c_float), ("dtype", C.c_int), ("tome_r", C.POINTER(C.c_int)),
+                ("range_stats", vp)]
 
 
 class ConvArgs(C.Structure):
@@ -151,6 +154,7 @@ def load() -> C.CDLL:
     lib.hm_nchw3_to_nhwc8.argtypes = [vp, vp, i, i, i, i, vp]
     lib.hm_gap_linear.argtypes = [vp, i, i, vp, C.c_float, vp, vp, i, i, vp]
     lib.hm_layernorm_accum.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, C.c_float, vp]
+    lib.hm_absmax16.argtypes = [vp, i, i, i, i, i, vp, vp]
     lib.hm_conv2d_nhwc.argtypes = [C.POINTER(ConvArgs), vp]
     lib.hm_conv_splitk_bytes.argtypes = [C.POINTER(ConvArgs)]
     lib.hm_conv_splitk_bytes.restype = C.c_size_t

@@ -67,6 +67,9 @@ typedef struct hm_gemm_args {
    * writes its partial product to C + s*M*ldc.  For small M (few output tiles, long K); the consumer adds the
    * slabs in order (hm_layernorm_accum), so the result is deterministic.  0 or 1: off. */
   int k_split;
+  /* HM_EPI_GELU only: C = gelu_erf(acc + bias) * out_scale, a power of two chosen at load so that the 16-bit activation stays
+   * finite (the consumer's weights carry 1 / out_scale; HamerEngine prescale).  0 or 1: off. */
+  float out_scale;
 } hm_gemm_args;
 
 /* nn.Linear forward on MFMA: C = epilogue(X . W^T).  Replaces the aten::addmm calls behind
@@ -139,6 +142,9 @@ int hm_layernorm(const float* x, const float* gamma, const float* beta, void* ou
  * out = LayerNorm(x) as hm_layernorm.  x is updated in place. */
 int hm_layernorm_accum(float* x, const float* partials, int n_partials, const float* bias, const float* gamma,
                        const float* beta, void* out, int out_dtype, int M, int D, float eps, void* stream);
+/* max |x[m][col0 + c]| over m < M, c < ncols of a 16-bit matrix with row pitch ld, folded into *slot (device, >= 0 on entry)
+ * with an atomic max: the range probe of hm_hamer_weights.range_stats. */
+int hm_absmax16(const void* x, int ld, int M, int col0, int ncols, int dtype, float* slot, void* stream);
 
 /* Attention.forward core (vit.py:115-123): softmax(scale q k^T) v for `tokens`=192 keys.
  * qkv [B*tokens][3*heads*head_dim] 16-bit, column = which*H*d + head*d + i (reshape at
@@ -252,6 +258,12 @@ typedef struct hm_vit_block {
    * kmean_w: f32 [80][embed_dim]; kmean_b: f32 [80]. */
   const float* kmean_w;
   const float* kmean_b;
+  /* range prescale (round 4; 0 = 1): powers of two folded into the weights at load so that every 16-bit activation of the
+   * block stays inside fp16 on checkpoints whose activations overflow it.  attn_scale_mul multiplies the softmax scale (q and k
+   * rows were scaled down by 2^-aq, 2^-ak: attn_scale_mul = 2^(aq+ak)); gelu_out_scale is hm_gemm's out_scale for fc1
+   * (fc2.weight carries its inverse).  Everything else (LayerNorm gamma / beta against the next weight's columns, v rows
+   * against proj) is weight folding only. */
+  float attn_scale_mul, gelu_out_scale;
 } hm_vit_block;
 
 typedef struct hm_dec_layer {
@@ -263,6 +275,7 @@ typedef struct hm_dec_layer {
   const float* ca_q_w;
   const float *ca_out_w, *ca_out_b;
   const float *ff1_w, *ff1_b, *ff2_w, *ff2_b;
+  float ca_scale_mul;     /* range prescale (0 = 1): this layer's key rows of kv_w were scaled by 2^-a, the cross-attention scale takes 2^a */
 } hm_dec_layer;
 
 typedef struct hm_hamer_weights {
@@ -288,6 +301,10 @@ typedef struct hm_hamer_weights {
   /* token merging (HAMER_INFER(token_merge=True), hamer.py:481-483): host array of `depth` ints, the tokens to merge away
    * after the attention of each block (parse_r of selective_vit_adapter.py:132-157), or NULL for the dense backbone */
   const int* tome_r;
+  /* calibration (load time only): device array of 6 * depth + 1 + 2 * dec_depth floats, zeroed by the caller, or NULL.  When
+   * set (dense 16-bit path only), the forward also records the largest magnitude of every 16-bit activation class:
+   * per block [LN1 out, q, k, v, LN2 out, GELU out], then last_norm out, then per decoder layer [k, v] of the to_kv output. */
+  float* range_stats;
 } hm_hamer_weights;
 
 typedef struct hm_hamer_outputs {

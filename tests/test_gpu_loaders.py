@@ -143,22 +143,32 @@ def test_detector_from_checkpoint_file_equals_synthetic_route(tmp_path):
     np.testing.assert_allclose(pa[:, 2:4].cpu().numpy(), 1.5 * pf[:, 2:4].cpu().numpy(), rtol=1e-6)
 
 
-def test_fp16_overflow_is_detected_at_load_and_falls_back_to_bf16():
-    """the default operand type is fp16 (65504 ceiling, no overflow detection in the kernels).  HAMER.to() runs one
-    calibration forward; a checkpoint whose activations do not fit (here: a GELU input pushed to 1e5 by the fc1 bias of block
-    0) makes it warn and rebuild the engine with bfloat16 operands, whose outputs are finite."""
+def test_fp16_overflow_is_detected_at_load_and_rescaled_or_falls_back_to_bf16():
+    """ADVICE r2 / VERDICT r3 item 4: the default operand type is fp16 (65504 ceiling, no overflow detection in the kernels).
+    HAMER.to() runs one calibration forward; a checkpoint whose activations do not fit (here: a GELU input pushed to 1e5 by the
+    fc1 bias of block 0) makes it measure every activation class with a bf16 engine and rebuild the fp16 engine with powers of
+    two folded into the weights -- fp16 operands are kept.  Token merging has no prescale path: there the old fallback to
+    bfloat16 operands remains."""
     from hamer_yolo_amd.hamer.configs import get_config
     from hamer_yolo_amd.hamer.models.mano_wrapper import MANO
     cfg = synth.tiny_config()
     sd = synth.hamer_state_dict(cfg, seed=0)
     ok = HAMER(get_config(None), sd, MANO.synthetic(0), hamer_cfg=cfg).to("cuda")
-    assert ok.dtype == torch.float16                                   # the synthetic weights fit
+    assert ok.dtype == torch.float16 and ok._engine.prescale is None      # the synthetic weights fit
     bad = dict(sd)
     bad["backbone.blocks.0.mlp.fc1.bias"] = sd["backbone.blocks.0.mlp.fc1.bias"] + 1e5
     m = HAMER(get_config(None), bad, MANO.synthetic(0), hamer_cfg=cfg)
-    with pytest.warns(UserWarning, match="overflows fp16"):
+    with pytest.warns(UserWarning, match="rescaled by powers of two"):
         m.to("cuda")
-    assert m.dtype == torch.bfloat16
+    assert m.dtype == torch.float16 and m._engine.dtype == torch.float16
+    pre = m._engine.prescale
+    assert pre["blocks"][0]["gelu"] >= 4 and all(b["gelu"] == 0 for b in pre["blocks"][1:])     # 1e5 -> <= 4096: 2^-5; nothing else moved
     img = synth.normalize_crops(synth.crops_u8(2, seed0=1)).cuda()
     out, _ = m({"img": img})
+    assert torch.isfinite(out["pred_vertices"]).all()
+    mt = HAMER(get_config(None), bad, MANO.synthetic(0), hamer_cfg=cfg, token_merge=[1] * cfg.vit.depth)
+    with pytest.warns(UserWarning, match="falling back to bfloat16"):
+        mt.to("cuda")
+    assert mt.dtype == torch.bfloat16
+    out, _ = mt({"img": img})
     assert torch.isfinite(out["pred_vertices"]).all()
