@@ -134,7 +134,10 @@ class hamer_inference():
         n = len(boxes)
         if n == 0:
             raise ValueError("Invalid detections format")
-        rec = ops.crop_boxes(boxes, P).to(self.device)             # one upload for all hands
+        # one upload for all hands, from page-locked memory and asynchronous: a pageable host -> device copy makes the host wait
+        # for everything already queued on its stream -- with several HaMeR batches queued per stream that was a whole forward
+        # (tools/probes/e2e_trace.py: the third batch of a pass could not be enqueued before the first had finished)
+        rec = self._up(ops.crop_boxes(boxes, P))
         rsz = rec.numel() // n
         img = torch.empty(n, 3, P, P, device=self.device, dtype=torch.float32)
         off = 0
@@ -153,6 +156,13 @@ class hamer_inference():
             'do_flip': torch.tensor(flips, dtype=torch.float32),
             'frame_index': torch.tensor(fidx, dtype=torch.long),
         }
+
+    def _up(self, t: torch.Tensor) -> torch.Tensor:
+        """Host tensor -> device without blocking the host: through page-locked memory, asynchronously on the current stream
+        (the caching host allocator keeps the staging block alive until the copy has run)."""
+        if self.device.type != "cuda" or t.is_cuda:
+            return t.to(self.device)
+        return t.pin_memory().to(self.device, non_blocking=True)
 
     def prepare_batch_bbox(self, img_0: np.ndarray, bboxs: List) -> Dict[str, torch.Tensor]:
         """infer.py:154-259.  img_0: HxWx3 uint8 BGR; bboxs: [[label, [x1, y1, x2, y2]], ...]."""
@@ -182,7 +192,7 @@ class hamer_inference():
     def _estimate(self, batch, k_real=None, depth_refine=None):
         for key in batch:
             if isinstance(batch[key], torch.Tensor):
-                batch[key] = batch[key].to(self.device).float()
+                batch[key] = self._up(batch[key]).float()
         # the intrinsics go up BEFORE the forward is queued: a pageable host -> device copy waits for everything already on the
         # stream, and behind `self.model(batch)` that is the whole HaMeR forward -- 19 ms per chunk during which the driver could
         # not start the next chunk (d_infer flow: 1960 -> hands/s see DESIGN.md); a numpy K is uploaded once and kept
@@ -240,13 +250,17 @@ class hamer_inference():
 
 
 # ---------------------------------------------------------------------------------------- batch drivers
+import threading as _threading
+_scratch = _threading.local()          # per decoder thread: one reusable read buffer (see _read_bmp24)
+
+
 def _read_bmp24(path: str, alloc=None) -> Optional[np.ndarray]:
     """Uncompressed 24-bit BMP (what frame dumps usually are) straight into an HxWx3 BGR array: the file already holds BGR rows
     (bottom-up, padded to 4 bytes), so this is one strided copy instead of PIL's decode + RGB conversion + channel reversal
     (3 ms instead of 35 ms per 1080p frame on the build host).  None for anything else.  ``alloc(shape)`` may supply the
     destination array (the folder drivers hand out page-locked slots, so the strided copy IS the staging copy)."""
     import struct
-    with open(path, "rb") as f:
+    with open(path, "rb", buffering=0) as f:
         head = f.read(54)
         if len(head) < 54 or head[:2] != b"BM":
             return None
@@ -255,12 +269,31 @@ def _read_bmp24(path: str, alloc=None) -> Optional[np.ndarray]:
         if hsize < 40 or planes != 1 or bpp != 24 or comp != 0 or w <= 0 or h == 0:
             return None
         stride = (w * 3 + 3) & ~3
+        dst = alloc((abs(h), w, 3)) if alloc is not None else None
+        if dst is not None:
+            # file -> this decoder thread's reusable scratch (readinto: no 6 MB allocation per frame, whose page faults serialise
+            # the decoder threads on the process's memory map) -> one flipped copy into the destination slot.  Measured and
+            # dropped: a scatter read straight into the slot (os.preadv, one iovec per row: 10x slower into page-locked memory)
+            # and a read-only mapping of the file (mmap / munmap per frame: the same memory-map contention between threads).
+            n = stride * abs(h)
+            sc = getattr(_scratch, "buf", None)
+            if sc is None or sc.size < n:
+                sc = _scratch.buf = np.empty(n, dtype=np.uint8)
+            f.seek(off)
+            view, got = memoryview(sc)[:n], 0
+            while got < n:
+                k = f.readinto(view[got:])
+                if not k:
+                    return None
+                got += k
+            rows = sc[:n].reshape(abs(h), stride)[:, :w * 3].reshape(abs(h), w, 3)
+            np.copyto(dst, rows[::-1] if h > 0 else rows)
+            return dst
         f.seek(off)
         buf = f.read(stride * abs(h))
     if len(buf) < stride * abs(h):
         return None
     rows = np.frombuffer(buf, dtype=np.uint8).reshape(abs(h), stride)[:, :w * 3].reshape(abs(h), w, 3)
-    dst = alloc((abs(h), w, 3)) if alloc is not None else None
     if dst is None:
         return np.ascontiguousarray(rows[::-1] if h > 0 else rows)
     np.copyto(dst, rows[::-1] if h > 0 else rows)
@@ -451,6 +484,13 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
         new_event, stream_ctx = _Cpu.Event, _Cpu.ctx
     st = stats if stats is not None else {}
     st.update(images=len(image_paths), frames=0, hands=0, det_passes=0, forwards=0)
+    import time as _time
+    _t0 = _time.perf_counter()
+    trace = st.setdefault("trace", []) if os.environ.get("HAMER_E2E_TRACE") == "1" else None      # (host timeline of a pass, ms: tuning runs)
+
+    def mark(what):
+        if trace is not None:
+            trace.append((round((_time.perf_counter() - _t0) * 1e3, 2), what))
 
     ahead = max(4 * first_pass, big_pass + first_pass)                       # decode-ahead window, in files
     ring = _FrameRing(min(max(1, len(image_paths)), ahead + 2 * big_pass), pin=on_gpu)
@@ -508,6 +548,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             done = new_event()
             done.record(dstream)
         st["det_passes"] += 1
+        mark(f"det_enqueued {len(items)}")
         return {"items": items, "frames": frames, "token": token, "done": done}
 
     def det_harvest(job):
@@ -522,6 +563,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             else:                                                  # any object with the reference's detect(image) works too
                 dets_lists = [detector.detect(im)[1] for _, im, _ in items]
         job["done"].synchronize()        # the pass's uploads and kernels are complete: its frames may be read from any stream
+        mark(f"det_harvested {len(items)}")
         found = 0
         for (fi, _, _), fr, dl in zip(items, frames, dets_lists):
             dl = [d for d in _detection_list(dl) if box_has_area(d)]
@@ -559,11 +601,15 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             mp = out['pred_mano_params']
             dev_res = {'betas': mp['betas'], 'global_orient': mp['global_orient'], 'hand_pose': mp['hand_pose'],
                        'cam_t': out['pred_cam_t_full'], 'do_flip': out['do_flip']}
+            done = new_event()
+            done.record(stream)          # (its own event: a stream synchronise would also wait for the NEXT batch queued on that stream)
         st["forwards"] += 1
-        return {"stream": stream, "hands": [(fi, j) for fi, j, _ in hands], "dev": dev_res, "frames": frames}   # (frames: alive until finish)
+        mark(f"batch_enqueued {len(hands)}")
+        return {"done": done, "hands": [(fi, j) for fi, j, _ in hands], "dev": dev_res, "frames": frames}   # (frames: alive until finish)
 
     def batch_finish(job):
-        job["stream"].synchronize()
+        job["done"].synchronize()
+        mark(f"batch_done {len(job['hands'])}")
         res = {k: v.detach().cpu().numpy() for k, v in job["dev"].items()}
         n = res['betas'].shape[0]
         res['pose_global'] = rodrigues_log_batch(res['global_orient'].reshape(n, 3, 3))
@@ -688,6 +734,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             elif not frames_left and not queue:
                 break
         yield from emit_ready()
+        mark("end")
 
 
 def _record_from(hands: Dict, i: int, is_right: bool) -> Dict:

@@ -218,6 +218,20 @@ def test_batch64_is_batch_invariant():
         # behind it is a 5e-4 relative step: measured 3.6e-5 on the outputs)
         np.testing.assert_allclose(b[:16].cpu().numpy(), a.cpu().numpy(), atol=2e-4, rtol=0)
         np.testing.assert_allclose(o8[k].cpu().numpy(), b[:8].cpu().numpy(), atol=5e-4, rtol=0)
+    # Round 4: the tight statement, per kernel family.  (i) Batches that take the SAME kernels give the same bytes: 64 vs 128
+    # hands (whole 256-row tiles: persistent store / GELU GEMMs, in-loop residual), 16 vs 32 hands (128 x 128 tile, residual in the
+    # epilogue).  (ii) What separates 64 from 16 is one thing only, the position of the fp32 residual add (inside the K loop of
+    # gemm_x3r_kernel from whole tiles on; behind it otherwise): with HM_OPT_RESID_IN_EPILOGUE = 1 -- the round-2 form, same
+    # position at every batch size -- 64 hands equal 16 hands to 2e-5 again.
+    o32 = {k: v.clone() for k, v in eng.forward(img16.repeat(2, 1, 1, 1)).items()}
+    o128 = {k: v.clone() for k, v in eng.forward(img16.repeat(8, 1, 1, 1)).items()}
+    with L.option(L.HM_OPT_RESID_IN_EPILOGUE, 1):
+        o64e = {k: v.clone() for k, v in eng.forward(img64).items()}
+    torch.cuda.synchronize()
+    for k in ("pose6d", "betas", "pred_cam", "pred_vertices", "pred_keypoints_3d"):
+        assert torch.equal(o128[k][:16], o64[k][:16]) and torch.equal(o128[k][112:], o64[k][:16]), k
+        np.testing.assert_allclose(o32[k][:16].cpu().numpy(), o16[k].cpu().numpy(), atol=2e-5, rtol=0)
+        np.testing.assert_allclose(o64e[k][:16].cpu().numpy(), o16[k].cpu().numpy(), atol=2e-5, rtol=0)
     r = o64["rotmats"]
     eye = torch.eye(3, device="cuda").expand_as(r)
     np.testing.assert_allclose((r @ r.transpose(-1, -2)).cpu().numpy(), eye.cpu().numpy(), atol=1e-5)
@@ -370,7 +384,9 @@ def test_tome_vith_geometry_vs_oracle_nondegenerate_schedule():
     # permutation: 8 blocks x 96 proposals ranked per crop leave near-ties that last-bit differences of the fp32 residual stream
     # (accumulation order of the 16-bit GEMMs) resolve differently, and with random-init weights ONE flipped merge moves the
     # regressed pose by ~1e-2.  On the 6-block geometry the same code tracks its oracle to 8e-6 (test above).
-    assert d_emu < 5e-2 and d_32 < 5e-2 and d_b32 < 5e-2
+    # Bounds = the measured level with a 1.6x margin (round 4; they were a blanket 5e-2): a merge BUG -- wrong partner, wrong size
+    # weight, a dropped token -- moves the pose by 1e-1 and more on these weights (debug runs of tools/debug_tome.py).
+    assert d_emu < 2.1e-2 and d_32 < 3.5e-2 and d_b32 < 2.1e-2
 
 
 def test_tome_vith_schedule_runs_to_one_token():

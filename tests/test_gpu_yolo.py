@@ -442,8 +442,20 @@ def test_forward_decode_vs_oracle_and_reference_golden(engine, golden_dir):
         assert float(d32.max()) < 0.3 and float(d32.mean()) < 0.02
     assert float((pred[:, 4:] - epred[0, :, 4:]).abs().max()) < 2e-2
     size = epred[0, :, 2:4].abs().mean(1, keepdim=True).clamp_min(8.0)
-    # wh = (2 sigma)^2 anchor doubles the relative logit error (round 3: 0.113 with the small maps' convolutions split over K --
-    # another fp32 summation order than the oracle's single pass)
+    # wh = (2 sigma)^2 anchor doubles the relative logit error.  The oracle sums every convolution in ONE pass over K; the product
+    # splits the small maps' convolutions over K ranges and K groups (another fp32 summation order: 0.113 measured).  So
+    # the 1e-1 bound of the single-pass order is asserted on the single-pass route (no split, no K groups), and the product route
+    # is tied to it by a bound that expresses nothing but the summation-order difference.
+    with L.option(L.HM_OPT_CONV_SPLITK, 1), L.option(L.HM_OPT_CONV_KGROUPS, 1):
+        p1 = engine.forward(frame.to(DEV))
+        torch.cuda.synchronize()
+        pred1 = p1["pred"].cpu().clone()
+    p = engine.forward(frame.to(DEV))
+    torch.cuda.synchronize()
+    pred = p["pred"].cpu()
+    assert float(((pred1[:, :4] - epred[0, :, :4]).abs() / size).max()) < 1e-1
+    assert float((pred1[:, 4:] - epred[0, :, 4:]).abs().max()) < 2e-2
+    assert float(((pred[:, :4] - pred1[:, :4]).abs() / size).max()) < 8e-2 and float((pred[:, 4:] - pred1[:, 4:]).abs().max()) < 1e-2
     assert float(((pred[:, :4] - epred[0, :, :4]).abs() / size).max()) < 1.5e-1
     # loose: the reference's own fp32 output rows
     ref_rows = torch.from_numpy(g["pred_rows"])
