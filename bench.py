@@ -414,9 +414,17 @@ def main():
         raise SystemExit(relaunch_under_torchrun(args.gpus))         # children do the work; nothing here has initialised HIP
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    rank, local, world = shard.init_distributed("nccl")
+    # HAMER_BENCH_REHEARSAL=1 (one-GPU box): the N > 1 code path with every rank on the one card and gloo as the backend (RCCL
+    # refuses two ranks on one device) -- a correctness rehearsal of the rank logic, never a measurement
+    rehearsal = os.environ.get("HAMER_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local0 = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local0)
+    rank, local, world = shard.init_distributed("gloo" if rehearsal else "nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if rehearsal:
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = torch.distributed

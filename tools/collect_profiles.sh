@@ -33,7 +33,7 @@ python3 tools/pmc_parse.py "$F" "$W" "$Mf" $OUT/pmc_$TAG/${TAG}_pmc_traffic.json
 cp "$F" $OUT/pmc_$TAG/fetch_size_counter_collection.csv; cp "$W" $OUT/pmc_$TAG/write_size_counter_collection.csv; cp "$Mf" $OUT/pmc_$TAG/mfma_busy_counter_collection.csv
 
 # 4. (round 3) the YOLOv7 detector pass: kernel trace of tools/prof_yolo.py for 16 frames of 1080p in one pass, and for one frame
-for F in 16 1; do
+for F in 16 1; do  # (round 4 adds 48 frames in tools/gpu/r04_collect.sh)
   mkdir -p $OUT/prof_${TAG}_yolo$F
   rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_yolo$F -o ${TAG}_yolo$F --output-format csv -- python3 tools/prof_yolo.py $F 3 > $OUT/prof_${TAG}_yolo$F/prof_yolo.log 2>&1 || exit 1
   tail -2 $OUT/prof_${TAG}_yolo$F/prof_yolo.log
