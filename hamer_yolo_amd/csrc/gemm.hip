@@ -35,6 +35,7 @@ struct KArgs {                                    // kernel-side view of either 
   const unsigned char* xs; const float* wscale; unsigned char* out_scales;   // hm_gemm_fp8
   const void* resid16; int ldr16;                 // HM_EPI_ADD_RELU: 16-bit residual (conv)
   int ksplit;                                     // HM_EPI_F32 only: K is cut into ksplit ranges, one workgroup and one [M][ldc] slab of C each
+  int general_loader;                             // CONV: 1 = the general implicit-GEMM loader even where the lean one applies (HM_OPT_CONV_GENERAL_LOADER: A/B runs, tests)
   float out_scale;                                // HM_EPI_GELU (16-bit out): C = gelu(acc + bias) * out_scale (a power of two; 1 = the plain epilogue)
   int kser;                                       // KSER kernels: the same ranges summed one after the other by ONE workgroup (0 / 1: one range)
   // convolution geometry (CONV only)
@@ -444,12 +445,52 @@ __global__ __launch_bounds__(64 * WM * WN * WK, WK > 1 ? 1 : 2) void gemm_tn_ker
   const int nk_all = EPI == HM_EPI_F32 ? g.K / BK / g.ksplit : g.K / BK;
   const int kt0 = split * nk_all;                       // split-K: this workgroup's K range starts kt0 tiles in
   const int nk = nk_all / WK;                           // steps of the loop (host: nk_all % WK == 0); group kg takes tile kt * WK + kg
+  // Round 4: the LEAN implicit-GEMM loader.  The general loader below derives (tap, ky, kx, ci), the bounds test and a 64-bit
+  // source address per lane, piece and K-step: ~100 vector / scalar instructions per wave and step (10 v_mul_lo_u32, 8
+  // v_mad_u64_u32, a division, five divergent branches) beside 32 MFMAs -- with two waves per SIMD the vector issue port, not
+  // the MFMA pipe, paced the convolutions (550-620 TFLOP/s on layers whose tiles run at 1000 as plain GEMMs).  With
+  // Cin % 64 == 0 (every layer but the first two, which have direct kernels) a 64-deep K-step lies inside ONE tap, so the K
+  // position is wave-uniform: (tap, ky, kx, ci) advance in scalar registers from one stage() call to the next (the calls walk the
+  // K tiles in order, WK apart), the pixel part of the address is a per-lane pointer formed once (pcen), and "is this tap's pixel
+  // inside the image" is one bit of a per-lane mask formed once (vmask): per piece one 64-bit add, a bit test and a select.
+  const bool lean = CONV && g.cin_log2 >= 6 && g.taps <= 32 && !g.general_loader;
+  const elem* pcen[XI];
+  unsigned vmask[XI];
+  int s_ci = 0, s_kx = 0, s_ky = 0, s_tap = 0;
+  if (CONV) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      pcen[i] = xsrc[i] + ((ptrdiff_t)pix_y[i] * g.Wd + pix_x[i]) * g.ldx + chunk * 8;     // (only dereferenced under a valid tap)
+      unsigned cm = 0, m = 0;                              // in-image test is separable: column bits, then one copy per valid row
+      for (int kx = 0; kx < g.ksz; ++kx) cm |= ((unsigned)(pix_x[i] + kx) < (unsigned)g.Wd) ? (1u << kx) : 0u;
+      for (int ky = 0; ky < g.ksz; ++ky) m |= ((unsigned)(pix_y[i] + ky) < (unsigned)g.H) ? (cm << (ky * g.ksz)) : 0u;
+      vmask[i] = m;
+    }
+    const int k_first = (kt0 + (WK > 1 ? kg : 0)) * BK;
+    s_tap = k_first >> g.cin_log2;
+    s_ci = k_first & ((1 << g.cin_log2) - 1);
+    s_ky = s_tap / g.ksz;
+    s_kx = s_tap - s_ky * g.ksz;
+  }
   auto stage = [&](int buf, int kt) {
     if (SCHED == 93) return;                            // ablation: no global loads at all
     char* lx = smem + (kg * STAGES + buf) * STAGE_BYTES + wave * XI * 1024;
     char* lw = smem + (kg * STAGES + buf) * STAGE_BYTES + XTILE_BYTES + wave * WI * 1024;
     if (WK > 1) kt = kt * WK + kg;
-    if (CONV) {
+    if (CONV && lean) {
+      const ptrdiff_t delta = ((ptrdiff_t)s_ky * g.Wd + s_kx) * g.ldx + s_ci;        // wave-uniform
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const elem* src = ((vmask[i] >> s_tap) & 1u) ? pcen[i] + delta : (const elem*)g.zeros;
+        glds16(src, lx + i * 1024);
+      }
+      s_ci += BK * WK;                                   // the next call stages the K tile WK further on
+      while (s_ci >= (1 << g.cin_log2)) {
+        s_ci -= 1 << g.cin_log2;
+        ++s_tap;
+        if (++s_kx == g.ksz) { s_kx = 0; ++s_ky; }
+      }
+    } else if (CONV) {
       const int k = (kt0 + kt) * BK + chunk * 8;
       const int tap = k >> g.cin_log2, ci = k & ((1 << g.cin_log2) - 1);
       const int ky = tap / g.ksz, kx = tap - ky * g.ksz;
@@ -3759,6 +3800,7 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   k.M = c.N * Hout * Wout; k.N = c.Cout; k.K = c.Kpad; k.ldx = c.ldx; k.ldw = c.Kpad; k.ldc = c.ldy; k.ldr = 0; k.resid_mod = 0;
   k.zeros = c.zeros; k.H = c.H; k.Wd = c.W_in; k.Hout = Hout; k.Wout = Wout; k.ksz = c.ksize; k.stride = c.stride; k.pad = pad;
   k.cin_log2 = lg; k.taps = taps; k.group_m = g_group_m;
+  k.general_loader = hm_option(HM_OPT_CONV_GENERAL_LOADER) == 1;
   if (c.out_f32 && c.act) return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: f32 output has no activation");
   k.resid16 = c.resid; k.ldr16 = c.ldr;
   const int epi = c.out_f32 ? HM_EPI_F32 : (c.act == 1 ? HM_EPI_SILU : (c.act == 2 ? (c.resid ? HM_EPI_ADD_RELU : HM_EPI_RELU) : HM_EPI_STORE));

@@ -20,7 +20,8 @@ HM_VERSION = 400      # include/hamer_hip.h: load() refuses a library built from
 # tests/test_host_logic.py parses the header's enum and compares names and values with this table
 OPTION_NAMES = ("HM_OPT_PX_GRID", "HM_OPT_FP8P_GRID", "HM_OPT_FP8_ONE_TILE", "HM_OPT_FP8P_RESID", "HM_OPT_TOME_NO_SPLITK",
                 "HM_OPT_TOME_SCALAR_ATTENTION", "HM_OPT_RESID_IN_EPILOGUE", "HM_OPT_CONV_TILE", "HM_OPT_CONV_SPLITK",
-                "HM_OPT_PX_LDS_EPILOGUE", "HM_OPT_CONV_DIRECT", "HM_OPT_GEMM_TILE_RULE", "HM_OPT_CONV_KGROUPS")
+                "HM_OPT_PX_LDS_EPILOGUE", "HM_OPT_CONV_DIRECT", "HM_OPT_GEMM_TILE_RULE", "HM_OPT_CONV_KGROUPS",
+                "HM_OPT_CONV_GENERAL_LOADER")
 globals().update({_n: _i for _i, _n in enumerate(OPTION_NAMES)})
 
 EXPORTS = [

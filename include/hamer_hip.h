@@ -102,7 +102,8 @@ enum {
   HM_OPT_CONV_DIRECT = 10,          /* direct kernels (3x3: 3(8) -> 32 stem, 64 -> 64 stride 1, 32 -> 64 stride 2; 1x1 with K, Cout in {128, 256}): 0 = all, each from its own tile count up, 1 = none (implicit GEMM everywhere), 2 = stem only, 3 = all at any size */
   HM_OPT_GEMM_TILE_RULE = 11,       /* tuning: 1 = round 2's GEMM tile rule (256 x 256 only from 85 % full rounds), 0 = the rate model */
   HM_OPT_CONV_KGROUPS = 12,         /* tuning: 1 = no K groups inside a convolution workgroup (small maps), 0 = automatic */
-  HM_OPT_COUNT = 13
+  HM_OPT_CONV_GENERAL_LOADER = 13,  /* tuning / tests: 1 = the implicit-GEMM convolution takes its general loader (per-lane tap arithmetic every K-step) even where the lean one applies (Cin % 64 == 0); 0 = automatic.  Same bytes either way */
+  HM_OPT_COUNT = 14
 };
 int hm_set_option(int key, int value);
 int hm_get_option(int key);

@@ -135,6 +135,31 @@ def test_conv_k_groups_exact_and_close(tile):
     assert (base - ref).abs().max() < 2e-3 and (plain - ref).abs().max() < 2e-3 and (base - plain).abs().max() < 2e-3
 
 
+@pytest.mark.parametrize("Ci,Co,k,s,H,W", [(64, 64, 3, 1, 23, 37), (128, 72, 3, 2, 47, 79), (256, 128, 1, 1, 24, 40), (128, 96, 5, 1, 13, 13),
+                                           (512, 264, 3, 1, 12, 20), (64, 40, 3, 2, 9, 11)])
+def test_conv_lean_loader_equals_the_general_loader(Ci, Co, k, s, H, W):
+    """Round 4: with Cin % 64 == 0 a 64-deep K-step of the implicit GEMM lies inside one tap, and the lean loader keeps the K
+    position in scalar registers and the in-image test as one bit of a per-lane mask (one 64-bit add, a bit test and a select per
+    piece and K-step instead of ~25 instructions).  Same copies, same order: the bytes must equal the general loader's
+    (HM_OPT_CONV_GENERAL_LOADER = 1) -- odd map sizes (every border case of the mask), stride 2, 1x1 / 3x3 / 5x5, ragged Cout,
+    channel slices of wider buffers, with and without split-K scratch; exact on integers."""
+    x = synth.uniform("lx", (3, Ci, H, W), 1.0, seed=Ci + H).half().float()
+    w = synth.uniform("lw", (Co, Ci, k, k), (3.0 / (Ci * k * k)) ** 0.5, seed=Co).half().float()
+    b = synth.uniform("lb", (Co,), 0.3, seed=k)
+    ws = torch.empty(8 * 3 * H * W * Co * 4, dtype=torch.uint8, device=DEV)
+    for kw in (dict(ld_extra=64, y_extra=8), dict(splitk_ws=ws)):
+        lean = _conv_gpu(x, w, b, k, s, act=True, dt=torch.float16, **kw)
+        with L.option(L.HM_OPT_CONV_GENERAL_LOADER, 1):
+            gen = _conv_gpu(x, w, b, k, s, act=True, dt=torch.float16, **kw)
+        assert torch.equal(lean, gen), (Ci, Co, k, s, kw.keys())
+    ref = F.silu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=k // 2)).float()
+    assert (lean - ref).abs().max() < 3e-3
+    xi = (torch.arange(3 * Ci * H * W).reshape(3, Ci, H, W) % 5 - 2).float()
+    wi = ((torch.arange(Co * Ci * k * k).reshape(Co, Ci, k, k) * 7 + torch.arange(Co)[:, None, None, None]) % 3 - 1).float()
+    bi = (torch.arange(Co) % 7 - 3).float()
+    assert torch.equal(_conv_gpu(xi, wi, bi, k, s, act=False, dt=torch.float16), F.conv2d(xi, wi, bi, stride=s, padding=k // 2).half().float())
+
+
 @pytest.mark.parametrize("Ci,Co,k,s,H,W,nb", [(1024, 512, 1, 1, 12, 20, 40),     # 1x1, K = 1024 -> 2 ranges (one chain each), 128 x 128 tile
                                               (256, 256, 3, 1, 12, 20, 72),      # 3x3, K = 2304 -> 4 ranges of 9 tiles: one chain each (odd count)
                                               (512, 264, 3, 1, 12, 20, 48),      # K = 4608 -> 4 ranges of 18 tiles: even / odd sets inside a range; ragged N

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4: lean implicit-GEMM loader -- every convolution test (YOLO, RootNet), then the per-layer tables
+set -o pipefail
+export TMPDIR=/tmp
+O=gpurun_out/r04k; mkdir -p $O
+timeout -k 10 900 python3 -m pytest tests/test_gpu_yolo.py tests/test_gpu_rootnet.py -x -q -m gpu > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
+tail -3 $O/t.log
+for F in 48 16 1; do
+  timeout -k 10 300 python3 tools/prof_yolo.py $F > $O/yolo$F.log 2>&1 || { tail -20 $O/yolo$F.log; exit 1; }
+  tail -2 $O/yolo$F.log
+done

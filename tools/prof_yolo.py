@@ -18,6 +18,7 @@ eng.split_k = os.environ.get("SPLITK_WS", "1") == "1"
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_TILE, int(os.environ.get("CONV_TILE", 0))))       # 1..6: force one tile for every layer
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_SPLITK, int(os.environ.get("CONV_SPLITK", 0))))   # 1: never split
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_KGROUPS, int(os.environ.get("CONV_KGROUPS", 0))))   # 1: no K groups inside a workgroup
+L.check(L.load().hm_set_option(L.HM_OPT_CONV_GENERAL_LOADER, int(os.environ.get("CONV_GENERAL", 0))))   # 1: the general implicit-GEMM loader everywhere
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_DIRECT, int(os.environ.get("CONV_DIRECT", 0))))   # 1: implicit GEMM everywhere, 2: direct stem only
 _chunk = torch.stack([synth.frame_u8(1080, 1920, seed=i) for i in range(F)]).cuda()      # as the folder drivers upload a chunk: slices of one
 frames = [_chunk[i] for i in range(F)]                                                    # tensor -> ONE letterbox launch per pass
