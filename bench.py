@@ -173,6 +173,8 @@ def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass
         def step(**kw):
             out_dir = os.path.join(root, f"out_r{rank}_{n_out[0]}")      # (a fresh folder per pass: no deletes inside the timed region)
             n_out[0] += 1
+            if getattr(args, "det_frames", 0):
+                kw.setdefault("det_frames", args.det_frames)
             if sar is not None:
                 return d_infer.process_batch_manopara(in_dir, out_dir, k_real, hamer=hi, detector=det, sar=sar, frames_per_step=F,
                                                       rank=rank, world=world, **kw), out_dir
@@ -252,7 +254,7 @@ def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass
                                               "d_infer.process_batch_manopara, detector boxes used as found") if sar is not None else
                                              ("BASELINE configs[2]: 1080p frames through yolo/detector.py YOLOv7 + HaMeR via "
                                               "infer.process_batch_manopara (the README entry point), detector boxes used as found"),
-                                 "first_detector_pass_frames": F, "detector_pass_frames": infer.DET_FRAMES, "hands_per_forward": infer.HANDS_PER_FORWARD,
+                                 "first_detector_pass_frames": F, "detector_pass_frames": getattr(args, "det_frames", 0) or infer.DET_FRAMES, "hands_per_forward": infer.HANDS_PER_FORWARD,
                                  "batches_in_flight": 2, "detector_weights": yolo_weights, "frames_per_rank_and_pass": per_rank,
                                  "parallelism": f"frames round-robin x{world}", "forwards_per_pass_rank0": st.get("forwards"),
                                  "detector_passes_per_pass_rank0": st.get("det_passes")},
@@ -406,6 +408,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the short runs of the other single-GPU BASELINE configurations ('side_configs')")
     ap.add_argument("--chunks", type=int, default=4, help="e2e: a pass (= a step) covers frames x chunks files per GPU")
+    ap.add_argument("--det-frames", type=int, default=0, help="e2e: frames per detector pass after the first (default: infer.DET_FRAMES)")
     ap.add_argument("--hands4", action="store_true", help="e2e: detector weights calibrated to ~4 hands per frame (configs[2]'s wording) instead of ~8.6")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

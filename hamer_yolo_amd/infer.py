@@ -369,7 +369,7 @@ def _detection_list(dets):
 # hands each stage the batch shape it is tuned for (round 4: the two stages no longer share a chunk):
 #   * images are decoded by a thread pool straight into page-locked slots, a rolling window ahead of the GPU;
 #   * DETECTOR PASSES: runs of consecutive frames of one size -- `frames_per_step` for the first pass (so the first HaMeR
-#     forward starts early), up to `det_frames` (64) afterwards (the 12x20 / 24x40 maps of YOLOv7 want many frames per launch: 394 TFLOP/s at 16 frames, 556 at 48, 591 at 64) --
+#     forward starts early), up to `det_frames` (48) afterwards (the 12x20 / 24x40 maps of YOLOv7 want many frames per launch: 394 TFLOP/s at 16 frames, 556 at 48, 591 at 64 -- but passes of 64 or 96 frames cost the 192-frame folder 1-4 % end to end, profiles/r04_e2e_det_frames_sweep.log) --
 #     go up as one copy and through ONE batched YOLOv7 pass + NMS on the detector's own stream; one host sync per pass
 #     returns all its box lists, and the hands join a queue in (file, detection) order;
 #   * HaMeR BATCHES: whenever `hands_per_forward` hands are queued, exactly that many -- across frame and pass boundaries --
@@ -379,7 +379,7 @@ def _detection_list(dets):
 # Multi-GPU (SURVEY 8e "frames round-robin per rank, YOLO run where the frame lives"): rank r of `world` takes files
 # r, r + world, ...; every rank runs this whole pipeline on its own GPU and writes its own files -- no data-path collective.
 FRAMES_PER_STEP = 16
-DET_FRAMES = 64
+DET_FRAMES = 48
 HANDS_PER_FORWARD = 64
 
 
