@@ -391,6 +391,21 @@ def _driver_streams(dev, n: int):
     return get_streams(dev, n)
 
 
+_POOLS: Dict[int, object] = {}
+
+
+def _decode_pool(nthreads: int):
+    """The decoder threads, created once per thread count and kept for the life of the process: a decoder's read scratch
+    (_read_bmp24) is thread-local, and a fresh pool per pass meant sixteen fresh 6 MB buffers whose first-touch page faults
+    serialise on the process's memory map -- 8.4 ms until the first 16 frames of a pass were decoded, against 3-4 ms with warm
+    threads (tools/probes/decode_rate.py, profiles/r04_decode_rate.log)."""
+    from concurrent.futures import ThreadPoolExecutor
+    pool = _POOLS.get(nthreads)
+    if pool is None:
+        pool = _POOLS[nthreads] = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="hm-decode")
+    return pool
+
+
 class _Cpu:
     """Stand-ins for stream / event on a host-only run of the driver (the world_size-2 CPU test drives it with stub models)."""
 
@@ -650,7 +665,8 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             files[emit_at] = {"dets": [], "rows": [], "out": 0}        # (drop the arrays)
             emit_at += 1
 
-    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+    pool = _decode_pool(nthreads)
+    if True:
         futs, submitted, uploaded, taken = deque(), 0, 0, 0
         carry = None                                                  # a decoded frame that did not fit the previous pass (other size)
 
