@@ -1288,7 +1288,9 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 //   guarantees M, N multiples of 256), issued after the copies W(t+1), X(t+2) of the last step; the first step of the next
 //   tile therefore waits vmcnt(16 + 4): everything but those stores and X(t+2).  An extra vector-memory operation
 //   anywhere (a spill, the next tile's bias request) only makes a counted wait stricter, never looser.
-template <class T, int EPI, bool DIRECT = true>
+// DMAW (experiments library, variant 34): waves 0..3 issue ALL copies (their own rows and those of the wave that shares their
+// SIMD, wave + 4), waves 4..7 none -- does a SIMD whose second wave never stalls in copy issue keep its MFMA pipe fuller?
+template <class T, int EPI, bool DIRECT = true, bool DMAW = false>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
@@ -1325,15 +1327,28 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     m0 = tm << 8; n0 = tn << 8;
   };
   auto dma_x = [&](int slot, const char* base) {
+    if constexpr (DMAW) { if (wave >= 4) return; }
     char* l = smem + XRING + slot * TILE_BYTES + wave * XI * 1024;
 #pragma unroll
     for (int i = 0; i < XI; ++i) glds16_hidden_s(base, xoff[i], l + i * 1024);
+    if constexpr (DMAW) {                                 // the rows of wave + 4: 4 * XI * 8 rows further on, same lane offsets
+      const char* b2 = base + (size_t)(4 * XI * 8) * g.ldx * 2;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) glds16_hidden_s(b2, xoff[i], l + 4 * XI * 1024 + i * 1024);
+    }
   };
   auto dma_w = [&](int slot, const char* base) {
+    if constexpr (DMAW) { if (wave >= 4) return; }
     char* l = smem + WRING + slot * TILE_BYTES + wave * WI * 1024;
 #pragma unroll
     for (int i = 0; i < WI; ++i) glds16_hidden_s(base, woff[i], l + i * 1024);
+    if constexpr (DMAW) {
+      const char* b2 = base + (size_t)(4 * WI * 8) * g.ldw * 2;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) glds16_hidden_s(b2, woff[i], l + 4 * WI * 1024 + i * 1024);
+    }
   };
+  const bool dbl = DMAW && wave < 4;                       // this wave's copy groups are 8 pieces, not 4: the counted waits double
   // cursors over the concatenated step sequence: X runs two steps ahead of the MFMAs, W one
   int xti = 0, xkt = 0, wti = 0, wkt = 0, m0, n0;
   origin(0, m0, n0);
@@ -1375,7 +1390,8 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   dma_x(0, xbase); next_x();
   dma_w(0, wbase); next_w();
   dma_x(1, xbase + (size_t)xkt * ROWB); next_x();
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (dbl) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 
   int gs = 0, xs = 0;                                  // global step, its X slot (gs % 3); W slot = gs & 1
   for (int ti = 0; ti < my; ++ti) {
@@ -1399,8 +1415,8 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     int xs_last = 0, ws_last = 0;
     for (int kt = 0; kt < nk; ++kt, ++gs) {
       if (gs > 0) {
-        if (kt == 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");           // 16 epilogue stores + X(gs+1) + the 2 bias loads may stay in flight
-        else if (gs + 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // X(gs+1)
+        if (kt == 0) { if (dbl) asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); }   // 16 epilogue stores + X(gs+1) + the 2 bias loads may stay in flight
+        else if (gs + 1 < S) { if (dbl) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // X(gs+1)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();                    // step gs complete in LDS; everyone is done with step gs-1's slots (and epilogue)
@@ -1416,7 +1432,8 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     // The bias pair landed long ago (the wait of step kt == 1 retired it; >= 16 copies were issued behind it).  This statement
     // is its fence: at most 12 operations are in flight here (X(gs+1), W(gs+1), X(gs+2)), so it never stalls, and it names the
     // two registers as read-write operands -- no use, copy or spill of them can be scheduled above it.
-    asm volatile("s_waitcnt vmcnt(12)" : "+v"(bias_lo), "+v"(bias_hi) :: "memory");
+    if constexpr (DMAW) asm volatile("s_waitcnt vmcnt(24)" : "+v"(bias_lo), "+v"(bias_hi) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" : "+v"(bias_lo), "+v"(bias_hi) :: "memory");
 
     // ---- epilogue: 64 x 128 per wave = 4 column groups of 32 x 2 half-strips of 32 rows, each through 4 KB of LDS (all
     // eight waves inside the last step's X slot; the wave's 128 bias values wait in 512 B of the last step's W slot).
@@ -1870,9 +1887,10 @@ int launch_px(const KArgs& g, hipStream_t s) {
   // and 3 % slower for the plain store (qkv 119.8 vs 116.4, kv 177.2 vs 170.9) -- so each epilogue takes its faster form.
   // HM_OPT_PX_LDS_EPILOGUE: 0 = that choice, 1 = always through LDS, 2 = always lane swaps.
   const int form = hm_option(HM_OPT_PX_LDS_EPILOGUE);
-  const bool staged = form == 1 || (form == 0 && (PIPE || EPI != HM_EPI_GELU));   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
+  const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || EPI != HM_EPI_GELU));   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
 #ifdef HM_ABLATIONS
-  auto kern = PIPE == 2 ? (staged ? gemm_pp_kernel<T, EPI, false, true> : gemm_pp_kernel<T, EPI, true, true>)
+  auto kern = PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true> : gemm_px_kernel<T, EPI, true, true>)
+            : PIPE == 2 ? (staged ? gemm_pp_kernel<T, EPI, false, true> : gemm_pp_kernel<T, EPI, true, true>)
             : PIPE ? (staged ? gemm_pp_kernel<T, EPI, false> : gemm_pp_kernel<T, EPI, true>)
                    : (staged ? gemm_px_kernel<T, EPI, false> : gemm_px_kernel<T, EPI, true>);
 #else
@@ -2402,9 +2420,9 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
       return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
 #ifdef HM_ABLATIONS
     // ---- experiments (correct results, measured and not adopted: DESIGN.md section 4); tools and opt-in tests only
-    case 27: case 33:                                                                  // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger), else as 24
+    case 27: case 33: case 34:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
-        if (px_ok(g)) return variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s);
+        if (px_ok(g)) return variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));
       }
       if constexpr (EPI == HM_EPI_RESID_F32) {
         if (off32_ok(g) && rin_ok(g)) return launch_rin<T>(g, s);
@@ -2473,7 +2491,7 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 33)) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 34)) return true;
 #endif
   return false;
 }
