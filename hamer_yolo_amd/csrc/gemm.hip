@@ -1290,7 +1290,10 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 //   anywhere (a spill, the next tile's bias request) only makes a counted wait stricter, never looser.
 // DMAW (experiments library, variant 34): waves 0..3 issue ALL copies (their own rows and those of the wave that shares their
 // SIMD, wave + 4), waves 4..7 none -- does a SIMD whose second wave never stalls in copy issue keep its MFMA pipe fuller?
-template <class T, int EPI, bool DIRECT = true, bool DMAW = false>
+// STAMP (experiments library, variant 35; a diagnostic build: in the product no stamp executes): wave 0 of every workgroup
+// records s_memtime (shader cycles) and s_memrealtime (100 MHz) around the kernel and around every tile's K loop into
+// g.ln_stats as [workgroup][6] uint64: {cycles, realtime ticks} of the whole kernel, {cycles, ticks, K-steps} of its K loops.
+template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
@@ -1310,6 +1313,8 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   const int run_lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_len = tq + (xcd < tr ? 1 : 0);
   const int my = li < run_len ? (run_len - li + per - 1) / per : 0;
   if (my == 0) return;
+  unsigned long long st_c0 = 0, st_r0 = 0, st_kc = 0, st_kr = 0, st_kn = 0;
+  if constexpr (STAMP) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   const int nk = g.K / 64, S = my * nk;
   const int wr = wave / WN, wc = wave % WN;
   const char* X = (const char*)g.X;
@@ -1413,6 +1418,8 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
 #pragma unroll
       for (int b = 0; b < MI; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     int xs_last = 0, ws_last = 0;
+    unsigned long long st_a = 0, st_b = 0;
+    if constexpr (STAMP) { st_a = __builtin_amdgcn_s_memtime(); st_b = __builtin_amdgcn_s_memrealtime(); }
     for (int kt = 0; kt < nk; ++kt, ++gs) {
       if (gs > 0) {
         if (kt == 0) { if (dbl) asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); }   // 16 epilogue stores + X(gs+1) + the 2 bias loads may stay in flight
@@ -1427,6 +1434,14 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
       substep(xs, ws, 1);
       xs_last = xs; ws_last = ws;
       xs = xs == 2 ? 0 : xs + 1;
+    }
+    if constexpr (STAMP) {
+      st_kc += __builtin_amdgcn_s_memtime() - st_a; st_kr += __builtin_amdgcn_s_memrealtime() - st_b; st_kn += nk;
+      if (ti + 1 == my && tid == 0) {                  // (the last tile's epilogue is not inside the kernel figure: stamped before it)
+        unsigned long long* o = (unsigned long long*)g.ln_stats + (size_t)blockIdx.x * 6;
+        o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        o[2] = st_kc; o[3] = st_kr; o[4] = st_kn; o[5] = my;
+      }
     }
     __builtin_amdgcn_s_barrier();                      // the last step's two slots are free: epilogue staging
     // The bias pair landed long ago (the wait of step kt == 1 retired it; >= 16 copies were issued behind it).  This statement
@@ -1887,9 +1902,11 @@ int launch_px(const KArgs& g, hipStream_t s) {
   // and 3 % slower for the plain store (qkv 119.8 vs 116.4, kv 177.2 vs 170.9) -- so each epilogue takes its faster form.
   // HM_OPT_PX_LDS_EPILOGUE: 0 = that choice, 1 = always through LDS, 2 = always lane swaps.
   const int form = hm_option(HM_OPT_PX_LDS_EPILOGUE);
-  const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || EPI != HM_EPI_GELU));   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
+  const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || EPI != HM_EPI_GELU));
+  if (PIPE == 4 && !g.ln_stats) return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 (stamps) needs a device buffer of 6 x 8 bytes per workgroup in ln_stats");   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
 #ifdef HM_ABLATIONS
-  auto kern = PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true> : gemm_px_kernel<T, EPI, true, true>)
+  auto kern = PIPE == 4 ? (staged ? gemm_px_kernel<T, EPI, false, false, true> : gemm_px_kernel<T, EPI, true, false, true>)
+            : PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true> : gemm_px_kernel<T, EPI, true, true>)
             : PIPE == 2 ? (staged ? gemm_pp_kernel<T, EPI, false, true> : gemm_pp_kernel<T, EPI, true, true>)
             : PIPE ? (staged ? gemm_pp_kernel<T, EPI, false> : gemm_pp_kernel<T, EPI, true>)
                    : (staged ? gemm_px_kernel<T, EPI, false> : gemm_px_kernel<T, EPI, true>);
@@ -2420,6 +2437,11 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
       return launch_cfg<T, EPI, 4, 2, 4, 8, 2, false, 64, 2>(g, s, "hm_gemm");
 #ifdef HM_ABLATIONS
     // ---- experiments (correct results, measured and not adopted: DESIGN.md section 4); tools and opt-in tests only
+    case 35:                                                                           // gemm_px_kernel with clock stamps (diagnostic)
+      if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
+        if (px_ok(g)) return launch_px<T, EPI, 4>(g, s);
+      }
+      return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 exists for the persistent kernel's shapes only");
     case 27: case 33: case 34:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
         if (px_ok(g)) return variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));
@@ -2491,7 +2513,7 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 34)) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 35)) return true;
 #endif
   return false;
 }
@@ -3734,6 +3756,9 @@ extern "C" int hm_gemm(const hm_gemm_args* a, void* stream_) {
     k.ksplit = g.k_split;
   }
   if (ln_out) { k.ln_gamma = g.ln_gamma; k.ln_xg = g.ln_xg; k.ln_stats = g.ln_stats; k.ln_P = g.N / 64; }
+#ifdef HM_ABLATIONS
+  if (g_variant == 35) k.ln_stats = g.ln_stats;      // (diagnostic build: the stamp buffer of gemm_px_kernel<..., STAMP>)
+#endif
   if (ln_in) {
     k.ln_stats = g.ln_stats; k.ln_colsum = g.ln_colsum;
   }
