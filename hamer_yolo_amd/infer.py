@@ -579,12 +579,15 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
                 dets_lists = [detector.detect(im)[1] for _, im, _ in items]
         job["done"].synchronize()        # the pass's uploads and kernels are complete: its frames may be read from any stream
         mark(f"det_harvested {len(items)}")
-        found = 0
-        for (fi, _, _), fr, dl in zip(items, frames, dets_lists):
+        kept = []                                  # (all frames' lists first, then the commit: a box that raises here must not
+        for fr, dl in zip(frames, dets_lists):     #  leave half a pass in the queue before the pass is redone file by file)
             dl = [d for d in _detection_list(dl) if box_has_area(d)]
             if depth_model is not None and dl:
                 ok = depth_model.valid_boxes(dl, int(fr.shape[1]), int(fr.shape[0]))
                 dl = [d for d, v in zip(dl, ok) if v]
+            kept.append(dl)
+        found = 0
+        for (fi, _, _), fr, dl in zip(items, frames, kept):
             files[fi] = {"dets": dl, "rows": [None] * len(dl), "out": len(dl)}
             for j in range(len(dl)):
                 queue.append((fi, j, fr))

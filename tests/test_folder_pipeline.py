@@ -222,3 +222,38 @@ def test_two_ranks_write_one_folder_on_gloo(folder, tmp_path):
             if a[label] is not None:
                 for k in a[label]:
                     np.testing.assert_array_equal(a[label][k], b[label][k])
+
+
+def test_one_bad_frame_or_hand_costs_only_itself(folder, capsys):
+    """The reference wraps every file and every hand in try / except (hamer/infer.py:1306-1316).  Here a detector pass that raises
+    is redone file by file and a HaMeR batch that raises frame by frame: the bad file / the bad frame's hands are dropped with a
+    message, everything else comes out exactly as in a clean run, nothing twice."""
+    base, _, _, _ = _collect(folder, hands_per_forward=8, frames_per_step=4, det_frames=6)
+    files = infer._list_images(folder)
+
+    class BadPassDetector(StubDetector):
+        def detect_frames(self, frames):                  # file 5's pixels poison whatever pass they ride in
+            if any(int(fr.numpy()[0, 0, 0]) == (5 * 5) % 7 and np.array_equal(fr.numpy(), _frame(5)) for fr in frames):
+                raise RuntimeError("corrupt frame")
+            return super().detect_frames(frames)
+
+    det, ham, got = BadPassDetector(), StubHamer(), {}
+    for p, d, h in infer.iter_folder_results(files, ham, det, hands_per_forward=8, frames_per_step=4, det_frames=6):
+        assert p not in got
+        got[p] = (d, h)
+    assert "corrupt frame" in capsys.readouterr().out
+    want = {k: v for k, v in base.items() if k != files[5]}
+    _same(want, got)
+
+    class BadHandHamer(StubHamer):
+        def estimate_from_frames(self, frames, dets_lists, k_real=None, depth_refine=None):
+            if any(np.array_equal(fr.numpy(), _frame(8)) for fr in frames):
+                raise ValueError("Invalid bbox format")
+            return super().estimate_from_frames(frames, dets_lists, k_real, depth_refine)
+
+    got = {}
+    for p, d, h in infer.iter_folder_results(files, BadHandHamer(), StubDetector(), hands_per_forward=8, frames_per_step=4, det_frames=6):
+        assert p not in got
+        got[p] = (d, h)
+    assert "Invalid bbox format" in capsys.readouterr().out
+    _same({k: v for k, v in base.items() if k != files[8]}, got)
