@@ -3565,8 +3565,30 @@ int pick_conv_tile(const KArgs& g, int ks_hint = 1, int wk = 1) {
   return t;
 }
 
+// `deep` (round 4): the 128 x 64 / 128 x 32 tiles of the two-accumulator-set and serial-range forms with a THREE-stage ring (72 /
+// 60 KB: still two workgroups per CU).  On the 12 x 20 maps of a 48-frame pass those layers are a few hundred workgroups of 18-72
+// K-steps each, and with one tile in flight a K-step lasts as long as its copy's round trip (~1 us); two tiles in flight halve
+// that.  Same K order: same bytes.  Chosen by launch_conv when the launch is at most one round of two workgroups per CU.
 template <class T, int EPI>
-int launch_conv_tile(const KArgs& g, int t, hipStream_t s) {
+int launch_conv_tile(const KArgs& g, int t, hipStream_t s, bool deep = false) {
+  if (deep) {
+    if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_SILU || EPI == HM_EPI_RELU || EPI == HM_EPI_F32) {
+      switch (t) {
+        case CT_128x32_P2: return launch_cfg<T, EPI, 2, 2, 4, 1, 3, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
+        case CT_128x64_P2: return launch_cfg<T, EPI, 2, 2, 4, 2, 3, true, 64, 0, 1, true>(g, s, "hm_conv2d_nhwc");
+        default: break;
+      }
+    }
+    if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_SILU || EPI == HM_EPI_RELU) {
+      switch (t) {
+        case CT_128x32_S: return launch_cfg<T, EPI, 2, 2, 4, 1, 3, true, 64, 0, 1, false, true>(g, s, "hm_conv2d_nhwc");
+        case CT_128x64_S: return launch_cfg<T, EPI, 2, 2, 4, 2, 3, true, 64, 0, 1, false, true>(g, s, "hm_conv2d_nhwc");
+        case CT_128x32_SP2: return launch_cfg<T, EPI, 2, 2, 4, 1, 3, true, 64, 0, 1, true, true>(g, s, "hm_conv2d_nhwc");
+        case CT_128x64_SP2: return launch_cfg<T, EPI, 2, 2, 4, 2, 3, true, 64, 0, 1, true, true>(g, s, "hm_conv2d_nhwc");
+        default: break;
+      }
+    }
+  }
   switch (t) {
     case CT_128x128: return launch_cfg<T, EPI, 2, 2, 4, 4, 2, true>(g, s, "hm_conv2d_nhwc");
     case CT_128x64: return launch_cfg<T, EPI, 2, 2, 4, 2, 2, true>(g, s, "hm_conv2d_nhwc");
@@ -3649,6 +3671,15 @@ int conv_split_rule(const KArgs& g) {
   return want < 1 ? 1 : want;
 }
 
+// deep ring for the narrow two-set / serial tiles: at most one round of two workgroups per CU, and enough K-steps per range
+bool conv_deep_ring(const KArgs& g, int t, int wgs, int nk_range) {
+  if (hm_option(HM_OPT_CONV_TILE) != 0) return false;                 // (a forced tile is taken as is: sweeps)
+  const bool narrow = t == CT_128x32_P2 || t == CT_128x64_P2 || t == CT_128x32_S || t == CT_128x64_S || t == CT_128x32_SP2 || t == CT_128x64_SP2;
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  return narrow && wgs <= 2 * cus && nk_range >= 6;
+}
+
 template <class T>
 int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStream_t s) {
   KArgs g = g0;
@@ -3667,22 +3698,25 @@ int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStr
   // the parallel split.
   if (ks > 1 && hm_option(HM_OPT_CONV_SPLITK) == 0) {
     int ts = g.N > 64 ? CT_128x128 : (g.N > 32 ? CT_128x64 : CT_128x32);
+    while (ts < CT_128x32 && conv_tiles(g, ts) < 192) ++ts;           // narrowed as pick_conv_tile narrows it
     if (conv_tiles(g, ts) >= 256) {
       g.kser = ks;
       const int t_ser = kgr == 2 ? (ts == CT_128x128 ? CT_128x128_SP2 : (ts == CT_128x64 ? CT_128x64_SP2 : CT_128x32_SP2))
                                  : (ts == CT_128x128 ? CT_128x128_S : (ts == CT_128x64 ? CT_128x64_S : CT_128x32_S));
+      const bool deep = conv_deep_ring(g, t_ser, conv_tiles(g, t_ser), g.K / 64 / ks);
       switch (epilogue) {
-        case HM_EPI_STORE: return launch_conv_tile<T, HM_EPI_STORE>(g, t_ser, s);
-        case HM_EPI_SILU: return launch_conv_tile<T, HM_EPI_SILU>(g, t_ser, s);
-        default: return launch_conv_tile<T, HM_EPI_RELU>(g, t_ser, s);
+        case HM_EPI_STORE: return launch_conv_tile<T, HM_EPI_STORE>(g, t_ser, s, deep);
+        case HM_EPI_SILU: return launch_conv_tile<T, HM_EPI_SILU>(g, t_ser, s, deep);
+        default: return launch_conv_tile<T, HM_EPI_RELU>(g, t_ser, s, deep);
       }
     }
   }
   const int t = pick_conv_tile(g, ks, kgr);
+  const bool deep = conv_deep_ring(g, t, conv_tiles(g, t) * (ks > 1 ? ks : 1), g.K / 64 / (ks > 1 ? ks : 1));
   if (ks > 1) {
     void* y = g.C; const int ldy = g.ldc; const float* bias = g.bias;
     g.C = ws; g.ldc = g.N; g.bias = nullptr; g.ksplit = ks;
-    if (const int rc = launch_conv_tile<T, HM_EPI_F32>(g, t, s)) return rc;
+    if (const int rc = launch_conv_tile<T, HM_EPI_F32>(g, t, s, deep)) return rc;
     const size_t n = (size_t)g.M * (g.N >> 3);
     const dim3 grid((unsigned)((n + 255) / 256));
     using elem = typename T::elem;
@@ -3692,10 +3726,10 @@ int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStr
     return hm_check_launch("hm_conv2d_nhwc (split-K reduce)");
   }
   switch (epilogue) {
-    case HM_EPI_STORE: return launch_conv_tile<T, HM_EPI_STORE>(g, t, s);
-    case HM_EPI_SILU: return launch_conv_tile<T, HM_EPI_SILU>(g, t, s);
-    case HM_EPI_F32: return launch_conv_tile<T, HM_EPI_F32>(g, t, s);
-    case HM_EPI_RELU: return launch_conv_tile<T, HM_EPI_RELU>(g, t, s);
+    case HM_EPI_STORE: return launch_conv_tile<T, HM_EPI_STORE>(g, t, s, deep);
+    case HM_EPI_SILU: return launch_conv_tile<T, HM_EPI_SILU>(g, t, s, deep);
+    case HM_EPI_F32: return launch_conv_tile<T, HM_EPI_F32>(g, t, s, deep);
+    case HM_EPI_RELU: return launch_conv_tile<T, HM_EPI_RELU>(g, t, s, deep);
     case HM_EPI_ADD_RELU: return launch_conv_tile<T, HM_EPI_ADD_RELU>(g, t, s);
     default: return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: unsupported epilogue");
   }
