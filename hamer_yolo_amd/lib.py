@@ -128,6 +128,14 @@ def load() -> C.CDLL:
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `python -m hamer_yolo_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the hot path.")
+    # torch FIRST: it ships its own HIP runtime (libamdhip64 under torch/lib).  Loaded before it, this library pulls in the
+    # system's copy and the process ends up with two runtimes -- torch sees the GPU, the kernels here fail with "no ROCm-capable
+    # device is detected" (seen when __graft_entry__.build() and smoke() ran in one process).  With torch's copy already mapped
+    # the loader resolves this library's HIP symbols to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

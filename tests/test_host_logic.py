@@ -89,6 +89,15 @@ def test_persistent_grid_option_is_not_sticky():
     assert lib.hm_get_option(L.HM_OPT_PX_GRID) == 0 and lib.hm_gemm_px_grid(720, 256) == 248
 
 
+def test_library_is_loaded_behind_torchs_hip_runtime():
+    """Round 4: loaded BEFORE torch, libhamer_hip.so maps the system's libamdhip64 and the process ends up with two HIP runtimes
+    (torch sees the GPU, the kernels here report "no ROCm-capable device": __graft_entry__.build() followed by smoke() in one
+    process).  lib.load() therefore imports torch first; checked in a fresh interpreter."""
+    code = "import sys; from hamer_yolo_amd import lib as L; assert 'torch' not in sys.modules; L.load(); assert 'torch' in sys.modules; print('ok')"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
 def test_abi_rejects_bad_arguments_without_gpu():
     lib = L.load()
     assert lib.hm_gemm(None, None) != 0
