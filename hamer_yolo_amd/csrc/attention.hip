@@ -43,15 +43,13 @@ template <class V4> __device__ __forceinline__ V4 lds_read_tr4(const void* p) {
   return __builtin_bit_cast(V4, v);
 }
 
-// LDS-DMA hidden from hipcc (inline asm; M0 = destination base, written and restored in the same statement).  Issued
+// LDS-DMA hidden from hipcc (inline asm; M0 = destination base, written in the same statement).  Issued
 // through the builtin, hipcc knows an LDS write is pending and puts vmcnt(0) in front of the next LDS read that might
 // alias it -- here the V reads of the item being computed, i.e. it would wait for the NEXT item's copy in the middle
 // of the math.  The copy's completion is counted by hand instead: wait_vm0() + barrier at the top of every step.
 __device__ __forceinline__ void glds16_hidden(const void* gsrc, void* lds_wave_base) {
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(dst) : "memory");   // (M0 overwritten, not saved: round 4, see gemm.hip)
 }
 
 // s_waitcnt vmcnt(0) through the builtin (simm16: expcnt and lgkmcnt fields at their maxima): hipcc's waitcnt pass

@@ -854,18 +854,24 @@ int launch_fp8(const KArgs& g, hipStream_t s) {
 // uniform base + 32-bit lane offset) and vmcnt is counted by hand: at the top of step t all but the newest 4 copies
 // (X of step t+1, issued after W(t) in step t-1) must have landed.
 // saddr forms: address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+// (Round 4: M0 is overwritten, not saved and restored -- hipcc initialises M0 in front of each of its own uses and never reads it
+//  back, and reading M0 right behind an LDS-DMA instruction is one more scalar dependency per piece.  Hot loops go further and
+//  pass the LDS destination as a scalar byte offset, glds16_lean_s below: interleaved A/B of the persistent GEMM, -1.4 %.)
 __device__ __forceinline__ void glds16_hidden_s(const char* base, unsigned off, void* lds_wave_base) {
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(dst) : "memory");
+}
+
+// The same copy with the LDS destination given as a byte offset already in a scalar register, and M0 simply overwritten: no
+// generic -> LDS pointer cast (hipcc guards that with a 64-bit null test per piece), no save / restore of M0 (the compiler
+// re-initialises M0 in front of each of its own uses and never reads it back) -- 3 scalar instructions per piece instead of 9.
+__device__ __forceinline__ void glds16_lean_s(const char* base, unsigned off, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(lds_dst) : "memory");
 }
 
 __device__ __forceinline__ void glds4_hidden_s(const char* base, unsigned off, void* lds_wave_base) {   // 4 bytes per lane
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(off), "s"(base), "s"(dst) : "memory");
 }
 
 template <class T, int EPI>
@@ -902,15 +908,15 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const KArgs g) {
   }
   auto dma_x = [&](int slot, int kt) {
     const char* base = X + (size_t)kt * ROWB;
-    char* l = smem + XRING + slot * TILE_BYTES + wave * XI * 1024;
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + XRING + slot * TILE_BYTES + wave * XI * 1024);
 #pragma unroll
-    for (int i = 0; i < XI; ++i) glds16_hidden_s(base, xoff[i], l + i * 1024);
+    for (int i = 0; i < XI; ++i) glds16_lean_s(base, xoff[i], l + i * 1024);
   };
   auto dma_w = [&](int slot, int kt) {
     const char* base = W + (size_t)kt * ROWB;
-    char* l = smem + WRING + slot * TILE_BYTES + wave * WI * 1024;
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + WRING + slot * TILE_BYTES + wave * WI * 1024);
 #pragma unroll
-    for (int i = 0; i < WI; ++i) glds16_hidden_s(base, woff[i], l + i * 1024);
+    for (int i = 0; i < WI; ++i) glds16_lean_s(base, woff[i], l + i * 1024);
   };
 
   f32x4_t acc[NI][MI];
@@ -1031,15 +1037,15 @@ __global__ __launch_bounds__(512, 2) void gemm_x3r_kernel(const KArgs g) {
   for (int i = 0; i < WI; ++i) woff[i] = (unsigned)(n0 + wave * WI * 8 + i * 8 + srow) * (unsigned)(g.ldw * 2) + swz * 16;
   auto dma_x = [&](int slot, int kt) {
     const char* base = X + (size_t)kt * ROWB;
-    char* l = smem + XRING + slot * TILE_BYTES + wave * XI * 1024;
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + XRING + slot * TILE_BYTES + wave * XI * 1024);
 #pragma unroll
-    for (int i = 0; i < XI; ++i) glds16_hidden_s(base, xoff[i], l + i * 1024);
+    for (int i = 0; i < XI; ++i) glds16_lean_s(base, xoff[i], l + i * 1024);
   };
   auto dma_w = [&](int slot, int kt) {
     const char* base = W + (size_t)kt * ROWB;
-    char* l = smem + WRING + slot * TILE_BYTES + wave * WI * 1024;
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + WRING + slot * TILE_BYTES + wave * WI * 1024);
 #pragma unroll
-    for (int i = 0; i < WI; ++i) glds16_hidden_s(base, woff[i], l + i * 1024);
+    for (int i = 0; i < WI; ++i) glds16_lean_s(base, woff[i], l + i * 1024);
   };
   // residual piece (ni, mi) of this wave: rows mb + 16 mi + (lane & 15), columns nb + 16 ni + 4 (lane >> 4) .. + 3
   const int mb = m0 + wr * 16 * MI, nb = n0 + wc * 16 * NI;
@@ -1293,7 +1299,9 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 // STAMP (experiments library, variant 35; a diagnostic build: in the product no stamp executes): wave 0 of every workgroup
 // records s_memtime (shader cycles) and s_memrealtime (100 MHz) around the kernel and around every tile's K loop into
 // g.ln_stats as [workgroup][6] uint64: {cycles, realtime ticks} of the whole kernel, {cycles, ticks, K-steps} of its K loops.
-template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false>
+// LEAN (round 4, the default; variant 36 of the experiments library compares it with the old form = LEAN false): the copies
+// through glds16_lean_s (LDS destinations as scalar byte offsets, M0 not saved / restored): -1.4 % per ViT block.
+template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false, bool LEAN = true>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
@@ -1331,9 +1339,16 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     tile_coords(run_lo + li + ti * per, tiles_m, tiles_n, g.group_m, tm, tn);
     m0 = tm << 8; n0 = tn << 8;
   };
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   auto dma_x = [&](int slot, const char* base) {
     if constexpr (DMAW) { if (wave >= 4) return; }
     char* l = smem + XRING + slot * TILE_BYTES + wave * XI * 1024;
+    if constexpr (LEAN) {
+      const unsigned d = __builtin_amdgcn_readfirstlane(lds_base + XRING + slot * TILE_BYTES + wave * XI * 1024);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) glds16_lean_s(base, xoff[i], d + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i) glds16_hidden_s(base, xoff[i], l + i * 1024);
     if constexpr (DMAW) {                                 // the rows of wave + 4: 4 * XI * 8 rows further on, same lane offsets
@@ -1345,6 +1360,12 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   auto dma_w = [&](int slot, const char* base) {
     if constexpr (DMAW) { if (wave >= 4) return; }
     char* l = smem + WRING + slot * TILE_BYTES + wave * WI * 1024;
+    if constexpr (LEAN) {
+      const unsigned d = __builtin_amdgcn_readfirstlane(lds_base + WRING + slot * TILE_BYTES + wave * WI * 1024);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) glds16_lean_s(base, woff[i], d + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < WI; ++i) glds16_hidden_s(base, woff[i], l + i * 1024);
     if constexpr (DMAW) {
@@ -1905,7 +1926,8 @@ int launch_px(const KArgs& g, hipStream_t s) {
   const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || EPI != HM_EPI_GELU));
   if (PIPE == 4 && !g.ln_stats) return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 (stamps) needs a device buffer of 6 x 8 bytes per workgroup in ln_stats");   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
 #ifdef HM_ABLATIONS
-  auto kern = PIPE == 4 ? (staged ? gemm_px_kernel<T, EPI, false, false, true> : gemm_px_kernel<T, EPI, true, false, true>)
+  auto kern = PIPE == 5 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, false> : gemm_px_kernel<T, EPI, true, false, false, false>)
+            : PIPE == 4 ? (staged ? gemm_px_kernel<T, EPI, false, false, true> : gemm_px_kernel<T, EPI, true, false, true>)
             : PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true> : gemm_px_kernel<T, EPI, true, true>)
             : PIPE == 2 ? (staged ? gemm_pp_kernel<T, EPI, false, true> : gemm_pp_kernel<T, EPI, true, true>)
             : PIPE ? (staged ? gemm_pp_kernel<T, EPI, false> : gemm_pp_kernel<T, EPI, true>)
@@ -2442,9 +2464,9 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
         if (px_ok(g)) return launch_px<T, EPI, 4>(g, s);
       }
       return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 exists for the persistent kernel's shapes only");
-    case 27: case 33: case 34:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
+    case 27: case 33: case 34: case 36:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
-        if (px_ok(g)) return variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));
+        if (px_ok(g)) return variant == 36 ? launch_px<T, EPI, 5>(g, s) : variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));   // (36: gemm_px_kernel with round 3's copy issue -- pointer casts, M0 saved and restored)
       }
       if constexpr (EPI == HM_EPI_RESID_F32) {
         if (off32_ok(g) && rin_ok(g)) return launch_rin<T>(g, s);
@@ -2513,7 +2535,7 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 35)) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 36)) return true;
 #endif
   return false;
 }
@@ -2729,9 +2751,7 @@ int launch_conv_direct(const KArgs& g, hipStream_t s) {
 // deep MFMA steps) and the epilogue arithmetic are the implicit GEMM's: results are bit-identical to it.
 __device__ __forceinline__ void glds16_hidden_v(const void* src, void* lds_wave_base) {
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");
 }
 
 // asm_store_note: the epilogues of the kernels below issue their 16-byte stores from inline asm (uniform base + lane offset).  A
