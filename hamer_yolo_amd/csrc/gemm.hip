@@ -525,9 +525,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, WK > 1 ? 1 : 2) void gemm_tn_ker
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
     vec8 wf[NI], xf[MI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
-#pragma unroll
     for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_sched_barrier(0);                 // X fragments first (round 4): the first MFMAs need W0 and all of X
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
     if (SCHED >= 1) __builtin_amdgcn_s_setprio(1);
 #ifdef HM_ABLATIONS
     if constexpr (SCHED == 98) {
@@ -931,9 +932,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const KArgs g) {
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
     vec8 wf[NI], xf[MI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
-#pragma unroll
     for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_sched_barrier(0);                 // X fragments first (round 4): the first MFMAs need W0 and all of X
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -1066,9 +1068,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3r_kernel(const KArgs g) {
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
     vec8 wf[NI], xf[MI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
-#pragma unroll
     for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_sched_barrier(0);                 // X fragments first (round 4): the first MFMAs need W0 and all of X
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -1225,9 +1228,10 @@ __global__ __launch_bounds__(512, 2) void gemm_d2_kernel(const KArgs g) {
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
     vec8 wf[NI], xf[MI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
-#pragma unroll
     for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_sched_barrier(0);                 // X fragments first (round 4): the first MFMAs need W0 and all of X
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -1301,7 +1305,10 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 // g.ln_stats as [workgroup][6] uint64: {cycles, realtime ticks} of the whole kernel, {cycles, ticks, K-steps} of its K loops.
 // LEAN (round 4, the default; variant 36 of the experiments library compares it with the old form = LEAN false): the copies
 // through glds16_lean_s (LDS destinations as scalar byte offsets, M0 not saved / restored): -1.4 % per ViT block.
-template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false, bool LEAN = true>
+// XFIRST (round 4, the default; variant 37 of the experiments library = the old order): the four X fragments of a sub-step are
+// read before the eight W fragments, so the first MFMAs (W0 x X0..3) issue behind five reads instead of nine and the remaining
+// W reads retire under them: -1.6 % per ViT block (profiles/r04_gemm_xfirst_ab.log).  Same MFMA order: same bytes.
+template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false, bool LEAN = true, bool XFIRST = true>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
@@ -1400,10 +1407,17 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     const char* lw = smem + WRING + wslot * TILE_BYTES;
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
     vec8 wf[NI], xf[MI];
+    if constexpr (XFIRST) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
+    if constexpr (!XFIRST) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+      for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -1926,7 +1940,8 @@ int launch_px(const KArgs& g, hipStream_t s) {
   const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || EPI != HM_EPI_GELU));
   if (PIPE == 4 && !g.ln_stats) return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 (stamps) needs a device buffer of 6 x 8 bytes per workgroup in ln_stats");   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
 #ifdef HM_ABLATIONS
-  auto kern = PIPE == 5 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, false> : gemm_px_kernel<T, EPI, true, false, false, false>)
+  auto kern = PIPE == 6 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, false> : gemm_px_kernel<T, EPI, true, false, false, true, false>)
+            : PIPE == 5 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, false> : gemm_px_kernel<T, EPI, true, false, false, false>)
             : PIPE == 4 ? (staged ? gemm_px_kernel<T, EPI, false, false, true> : gemm_px_kernel<T, EPI, true, false, true>)
             : PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true> : gemm_px_kernel<T, EPI, true, true>)
             : PIPE == 2 ? (staged ? gemm_pp_kernel<T, EPI, false, true> : gemm_pp_kernel<T, EPI, true, true>)
@@ -2464,9 +2479,9 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
         if (px_ok(g)) return launch_px<T, EPI, 4>(g, s);
       }
       return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 exists for the persistent kernel's shapes only");
-    case 27: case 33: case 34: case 36:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
+    case 27: case 33: case 34: case 36: case 37:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
-        if (px_ok(g)) return variant == 36 ? launch_px<T, EPI, 5>(g, s) : variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));   // (36: gemm_px_kernel with round 3's copy issue -- pointer casts, M0 saved and restored)
+        if (px_ok(g)) return variant == 37 ? launch_px<T, EPI, 6>(g, s) : variant == 36 ? launch_px<T, EPI, 5>(g, s) : variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));   // (36: gemm_px_kernel with round 3's copy issue -- pointer casts, M0 saved and restored)
       }
       if constexpr (EPI == HM_EPI_RESID_F32) {
         if (off32_ok(g) && rin_ok(g)) return launch_rin<T>(g, s);
@@ -2535,7 +2550,7 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 36)) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 37)) return true;
 #endif
   return false;
 }
