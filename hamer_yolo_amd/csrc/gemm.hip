@@ -1308,7 +1308,10 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 // XFIRST (round 4, the default; variant 37 of the experiments library = the old order): the four X fragments of a sub-step are
 // read before the eight W fragments, so the first MFMAs (W0 x X0..3) issue behind five reads instead of nine and the remaining
 // W reads retire under them: -1.6 % per ViT block (profiles/r04_gemm_xfirst_ab.log).  Same MFMA order: same bytes.
-template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false, bool LEAN = true, bool XFIRST = true>
+// R1EARLY (variant 38): the twelve fragment reads of the step's SECOND sub-step are issued in front of the step's copies instead of
+// behind them, so their latency passes under the copies' issue and the second run of MFMAs starts at once.
+// TWEAK (experiments): 1 = read order X0 W0 X1 X2 X3 W1.. (first MFMA behind two reads), 2 = no s_setprio around the MFMA runs.
+template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false, bool LEAN = true, bool XFIRST = true, bool R1EARLY = false, int TWEAK = 0>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
@@ -1407,6 +1410,17 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
     const char* lw = smem + WRING + wslot * TILE_BYTES;
     const int coff = ((ks * 4 + fch) ^ fsw) * 16;
     vec8 wf[NI], xf[MI];
+    if constexpr (TWEAK == 1) {
+      xf[0] = *(const vec8*)(lx + (wr * 16 * MI + frow) * ROWB + coff);
+      __builtin_amdgcn_sched_barrier(0);
+      wf[0] = *(const vec8*)(lw + (wc * 16 * NI + frow) * ROWB + coff);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 1; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 1; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
+    } else {
     if constexpr (XFIRST) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
@@ -1418,6 +1432,25 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
     }
+    }
+    if constexpr (TWEAK != 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = T::mfma(wf[ni], xf[mi], acc[ni][mi]);
+    if constexpr (TWEAK != 2) __builtin_amdgcn_s_setprio(0);
+  };
+  auto frag_reads = [&](int xslot, int wslot, int ks, vec8 (&wf)[NI], vec8 (&xf)[MI]) {
+    const char* lx = smem + XRING + xslot * TILE_BYTES;
+    const char* lw = smem + WRING + wslot * TILE_BYTES;
+    const int coff = ((ks * 4 + fch) ^ fsw) * 16;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) xf[i] = *(const vec8*)(lx + (wr * 16 * MI + i * 16 + frow) * ROWB + coff);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = *(const vec8*)(lw + (wc * 16 * NI + i * 16 + frow) * ROWB + coff);
+  };
+  auto frag_mfmas = [&](const vec8 (&wf)[NI], const vec8 (&xf)[MI]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -1463,10 +1496,19 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
       }
       __builtin_amdgcn_s_barrier();                    // step gs complete in LDS; everyone is done with step gs-1's slots (and epilogue)
       const int ws = gs & 1, xs2 = xs == 0 ? 2 : xs - 1;
+      if constexpr (R1EARLY) {
+        vec8 wf1[NI], xf1[MI];
+        substep(xs, ws, 0);
+        frag_reads(xs, ws, 1, wf1, xf1);
+        if (gs + 1 < S) { dma_w(ws ^ 1, wbase + (size_t)wkt * ROWB); next_w(); }
+        if (gs + 2 < S) { dma_x(xs2, xbase + (size_t)xkt * ROWB); next_x(); }
+        frag_mfmas(wf1, xf1);
+      } else {
       substep(xs, ws, 0);
       if (gs + 1 < S) { dma_w(ws ^ 1, wbase + (size_t)wkt * ROWB); next_w(); }   // W first, then X: the counted waits rely on this order
       if (gs + 2 < S) { dma_x(xs2, xbase + (size_t)xkt * ROWB); next_x(); }
       substep(xs, ws, 1);
+      }
       xs_last = xs; ws_last = ws;
       xs = xs == 2 ? 0 : xs + 1;
     }
@@ -1940,7 +1982,10 @@ int launch_px(const KArgs& g, hipStream_t s) {
   const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || EPI != HM_EPI_GELU));
   if (PIPE == 4 && !g.ln_stats) return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 (stamps) needs a device buffer of 6 x 8 bytes per workgroup in ln_stats");   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
 #ifdef HM_ABLATIONS
-  auto kern = PIPE == 6 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, false> : gemm_px_kernel<T, EPI, true, false, false, true, false>)
+  auto kern = PIPE == 9 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, false, 2> : gemm_px_kernel<T, EPI, true, false, false, true, true, false, 2>)
+            : PIPE == 8 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, false, 1> : gemm_px_kernel<T, EPI, true, false, false, true, true, false, 1>)
+            : PIPE == 7 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, true> : gemm_px_kernel<T, EPI, true, false, false, true, true, true>)
+            : PIPE == 6 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, false> : gemm_px_kernel<T, EPI, true, false, false, true, false>)
             : PIPE == 5 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, false> : gemm_px_kernel<T, EPI, true, false, false, false>)
             : PIPE == 4 ? (staged ? gemm_px_kernel<T, EPI, false, false, true> : gemm_px_kernel<T, EPI, true, false, true>)
             : PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true> : gemm_px_kernel<T, EPI, true, true>)
@@ -2479,9 +2524,9 @@ int launch_gemm(const KArgs& g, int variant, hipStream_t s) {
         if (px_ok(g)) return launch_px<T, EPI, 4>(g, s);
       }
       return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 exists for the persistent kernel's shapes only");
-    case 27: case 33: case 34: case 36: case 37:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
+    case 27: case 33: case 34: case 36: case 37: case 38: case 39: case 40:                                                         // persistent 256x256, software-pipelined K loop (gemm_pp_kernel; 33: + copy stagger); 34: gemm_px_kernel with all copies issued by waves 0..3; else as 24
       if constexpr (EPI == HM_EPI_STORE || EPI == HM_EPI_GELU) {
-        if (px_ok(g)) return variant == 37 ? launch_px<T, EPI, 6>(g, s) : variant == 36 ? launch_px<T, EPI, 5>(g, s) : variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));   // (36: gemm_px_kernel with round 3's copy issue -- pointer casts, M0 saved and restored)
+        if (px_ok(g)) return variant == 40 ? launch_px<T, EPI, 9>(g, s) : variant == 39 ? launch_px<T, EPI, 8>(g, s) : variant == 38 ? launch_px<T, EPI, 7>(g, s) : variant == 37 ? launch_px<T, EPI, 6>(g, s) : variant == 36 ? launch_px<T, EPI, 5>(g, s) : variant == 34 ? launch_px<T, EPI, 3>(g, s) : (variant == 33 ? launch_px<T, EPI, 2>(g, s) : launch_px<T, EPI, 1>(g, s));   // (36: gemm_px_kernel with round 3's copy issue -- pointer casts, M0 saved and restored)
       }
       if constexpr (EPI == HM_EPI_RESID_F32) {
         if (off32_ok(g) && rin_ok(g)) return launch_rin<T>(g, s);
@@ -2550,7 +2595,7 @@ int launch_gemm_ln(const KArgs& g, int variant, hipStream_t s) {
 bool variant_ok(int v) {
   if (v == -1 || v == 0 || v == 10 || v == 24 || v == 26) return true;
 #ifdef HM_ABLATIONS
-  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 37)) return true;
+  if ((v >= 1 && v <= 12) || (v >= 14 && v <= 18) || v == 20 || (v >= 21 && v <= 23) || v == 25 || (v >= 27 && v <= 40)) return true;
 #endif
   return false;
 }

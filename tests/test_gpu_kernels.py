@@ -146,7 +146,7 @@ def test_gemm_persistent_kernel_exact(dt):
     _persistent_kernel_exact(dt, 26)
 
 
-@pytest.mark.parametrize("pv", [27, 33, 34, 36, 37])
+@pytest.mark.parametrize("pv", [27, 33, 34, 36, 37, 38, 39, 40])
 def test_gemm_pipelined_persistent_experiment_exact(pv, experiments_lib):
     _persistent_kernel_exact(torch.float16, pv)
 
