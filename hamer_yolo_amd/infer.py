@@ -254,11 +254,14 @@ import threading as _threading
 _scratch = _threading.local()          # per decoder thread: one reusable read buffer (see _read_bmp24)
 
 
-def _read_bmp24(path: str, alloc=None) -> Optional[np.ndarray]:
+def _read_bmp24(path: str, alloc=None, raw_rows: Optional[list] = None) -> Optional[np.ndarray]:
     """Uncompressed 24-bit BMP (what frame dumps usually are) straight into an HxWx3 BGR array: the file already holds BGR rows
     (bottom-up, padded to 4 bytes), so this is one strided copy instead of PIL's decode + RGB conversion + channel reversal
     (3 ms instead of 35 ms per 1080p frame on the build host).  None for anything else.  ``alloc(shape)`` may supply the
-    destination array (the folder drivers hand out page-locked slots, so the strided copy IS the staging copy)."""
+    destination array (the folder drivers hand out page-locked slots, so the strided copy IS the staging copy).
+    ``raw_rows`` (a list, folder drivers): when the rows have no padding the pixel block is read with ONE readinto straight into the
+    destination and a bottom-up file is left bottom-up -- the list then receives True, and the caller flips the rows where that
+    is cheap (on the device, behind the upload: 16 frames are decoded in 2.0 ms instead of 4.7, tools/probes/decode_rate.py)."""
     import struct
     with open(path, "rb", buffering=0) as f:
         head = f.read(54)
@@ -270,6 +273,16 @@ def _read_bmp24(path: str, alloc=None) -> Optional[np.ndarray]:
             return None
         stride = (w * 3 + 3) & ~3
         dst = alloc((abs(h), w, 3)) if alloc is not None else None
+        if dst is not None and raw_rows is not None and stride == w * 3:
+            f.seek(off)
+            view, got = memoryview(dst.reshape(-1)), 0
+            while got < len(view):
+                k = f.readinto(view[got:])
+                if not k:
+                    return None
+                got += k
+            raw_rows.append(h > 0)                       # True: the rows in `dst` run bottom-up
+            return dst
         if dst is not None:
             # file -> this decoder thread's reusable scratch (readinto: no 6 MB allocation per frame, whose page faults serialise
             # the decoder threads on the process's memory map) -> one flipped copy into the destination slot.  Measured and
@@ -300,11 +313,11 @@ def _read_bmp24(path: str, alloc=None) -> Optional[np.ndarray]:
     return dst
 
 
-def _imread_bgr(path: str, alloc=None) -> Optional[np.ndarray]:
-    """cv2.imread stand-in (infer.py:1252): HxWx3 uint8 BGR, None when unreadable."""
+def _imread_bgr(path: str, alloc=None, raw_rows: Optional[list] = None) -> Optional[np.ndarray]:
+    """cv2.imread stand-in (infer.py:1252): HxWx3 uint8 BGR, None when unreadable.  (``raw_rows``: see _read_bmp24.)"""
     try:
         if path.lower().endswith(".bmp"):
-            im = _read_bmp24(path, alloc)
+            im = _read_bmp24(path, alloc, raw_rows)
             if im is not None:
                 return im
         from PIL import Image
@@ -515,8 +528,8 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
     hands_per_frame = 4.0                                             # running estimate, for how far ahead the detector runs
 
     def decode(index, path):
-        """One file -> (HxWx3 BGR array or None, its page-locked slot as a tensor or None)."""
-        taken = []
+        """One file -> (HxWx3 BGR array or None, its page-locked slot as a tensor or None, rows bottom-up?)."""
+        taken, raw = [], []
 
         def alloc(shape):
             got = ring.slot(index, shape)
@@ -524,13 +537,13 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
                 return None
             taken.append(got[0])
             return got[1]
-        im = _imread_bgr(path, alloc)
+        im = _imread_bgr(path, alloc, raw)
         if im is not None and not taken:                              # not decoded in place (PIL path): one copy into the slot
             got = ring.slot(index, im.shape)
             if got is not None:
                 np.copyto(got[1], im)
-                return got[1], got[0]
-        return im, (taken[0] if taken and im is not None else None)
+                return got[1], got[0], False
+        return im, (taken[0] if taken and im is not None else None), bool(raw and raw[0] and taken)
 
     # ------------------------------------------------------------------ detector passes
     def det_enqueue(first, items):
@@ -539,23 +552,29 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
         shape = items[0][1].shape
         with stream_ctx(dstream):
             if not on_gpu:                                         # (host-only run: the "upload" is a copy out of the ring)
-                frames = [torch.from_numpy(np.array(im, copy=True)) for _, im, _ in items]
-            elif all(t is not None for _, _, t in items):
+                frames = [torch.from_numpy(np.array(im[::-1] if rev else im, copy=True)) for _, im, _, rev in items]
+            elif all(t is not None for _, _, t, _ in items):
                 d = torch.empty((len(items),) + tuple(shape), dtype=torch.uint8, device=dev)
                 s0 = items[0][0] % ring.n
                 buf = ring.bufs[tuple(shape)][0]
-                if all(fi % ring.n == s0 + j for j, (fi, _, _) in enumerate(items)):
+                if all(fi % ring.n == s0 + j for j, (fi, _, _, _) in enumerate(items)):
                     d.copy_(buf[s0:s0 + len(items)], non_blocking=True)           # consecutive slots: ONE copy for the pass
                 else:
-                    for j, (_, _, t) in enumerate(items):
+                    for j, (_, _, t, _) in enumerate(items):
                         d[j].copy_(t, non_blocking=True)
                 ev = new_event()
                 ev.record(dstream)
-                for fi, _, _ in items:
+                for fi, _, _, _ in items:
                     ring.events[fi % ring.n] = ev
+                # frames the decoders left bottom-up (raw BMP rows, one read per file) are turned on the device: one flip of the
+                # pass's tensor when all of them are (the usual case), else frame by frame
+                if all(rev for _, _, _, rev in items):
+                    d = torch.flip(d, dims=(1,))
+                elif any(rev for _, _, _, rev in items):
+                    d = torch.stack([torch.flip(d[j], dims=(0,)) if items[j][3] else d[j] for j in range(len(items))])
                 frames = [d[j] for j in range(len(items))]
             else:
-                frames = [torch.from_numpy(np.ascontiguousarray(im)).to(dev) for _, im, _ in items]
+                frames = [torch.from_numpy(np.ascontiguousarray(im[::-1] if rev else im)).to(dev) for _, im, _, rev in items]
             if hasattr(detector, "detect_frames_enqueue"):
                 token = detector.detect_frames_enqueue(frames)
             else:
@@ -576,7 +595,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             elif hasattr(detector, "detect_frames"):
                 _, dets_lists = detector.detect_frames(frames)
             else:                                                  # any object with the reference's detect(image) works too
-                dets_lists = [detector.detect(im)[1] for _, im, _ in items]
+                dets_lists = [detector.detect(np.ascontiguousarray(im[::-1]) if rev else im)[1] for _, im, _, rev in items]
         job["done"].synchronize()        # the pass's uploads and kernels are complete: its frames may be read from any stream
         mark(f"det_harvested {len(items)}")
         kept = []                                  # (all frames' lists first, then the commit: a box that raises here must not
@@ -587,7 +606,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
                 dl = [d for d, v in zip(dl, ok) if v]
             kept.append(dl)
         found = 0
-        for (fi, _, _), fr, dl in zip(items, frames, kept):
+        for (fi, _, _, _), fr, dl in zip(items, frames, kept):
             files[fi] = {"dets": dl, "rows": [None] * len(dl), "out": len(dl)}
             for j in range(len(dl)):
                 queue.append((fi, j, fr))
@@ -669,7 +688,13 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             emit_at += 1
 
     pool = _decode_pool(nthreads)
-    if True:
+    # the interpreter hands the GIL over every 5 ms by default: with sixteen decoders and an enqueueing thread that is the time
+    # a decoder may wait before it even starts its (GIL-free) read -- 0.5 ms for the duration of the pass: the first detector
+    # pass goes out ~1 ms earlier (tools/gpu/r04_aa.sh)
+    import sys as _sys
+    _switch = _sys.getswitchinterval()
+    _sys.setswitchinterval(min(_switch, 0.0005))
+    try:
         futs, submitted, uploaded, taken = deque(), 0, 0, 0
         carry = None                                                  # a decoded frame that did not fit the previous pass (other size)
 
@@ -689,8 +714,8 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
                     it, carry = carry, None
                 elif taken < len(image_paths):
                     top_up()
-                    im, slot = futs.popleft().result()
-                    it = (taken, im, slot)
+                    im, slot, rev = futs.popleft().result()
+                    it = (taken, im, slot, rev)
                     taken += 1
                     if im is None:
                         files[it[0]] = {"dets": [], "rows": [], "out": 0}
@@ -754,6 +779,8 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
                 break
         yield from emit_ready()
         mark("end")
+    finally:
+        _sys.setswitchinterval(_switch)
 
 
 def _record_from(hands: Dict, i: int, is_right: bool) -> Dict:
