@@ -52,6 +52,33 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact-erf GELU (torch.nn.GELU default; vit.py:77, pose_transformer.py:45)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // v_rcp_f32, 1 ulp
+// The same SiLU on two / four values: the products and the sum go out as v_pk_mul_f32 / v_pk_add_f32 (two results per issue
+// slot), the two transcendentals stay per value -- ~24 issue cycles per value instead of ~32, and the convolution epilogues are
+// bound by exactly these (round 4: the stem pair kernel runs 102 SiLUs per lane and tile next to 128 MFMAs).  Every operation is
+// the one silu() performs (__expf(-x) IS v_exp_f32 of x * -log2(e)), so the results are bit-identical to it; the product is
+// pinned in fp32 before anything converts it (left alone hipcc may fuse a multiply and a 16-bit conversion into
+// v_fma_mixlo_f16: one rounding instead of two, other bits in one of ~10^4 values).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t silu2(f32x2_t x) {
+  const f32x2_t t = x * f32x2_t{-1.44269504088896340736f, -1.44269504088896340736f};
+  f32x2_t e;
+  e[0] = __builtin_amdgcn_exp2f(t[0]); e[1] = __builtin_amdgcn_exp2f(t[1]);
+  const f32x2_t d = e + f32x2_t{1.0f, 1.0f};
+  f32x2_t r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]); r[1] = __builtin_amdgcn_rcpf(d[1]);
+  f32x2_t p = x * r;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+__device__ __forceinline__ f32x4_t silu4(f32x4_t x) {
+  const f32x2_t lo = silu2(f32x2_t{x[0], x[1]}), hi = silu2(f32x2_t{x[2], x[3]});
+  return f32x4_t{lo[0], lo[1], hi[0], hi[1]};
+}
+// acc + bias for four values as two packed adds (the same IEEE additions as four __fadd_rn)
+__device__ __forceinline__ f32x4_t add4(f32x4_t a, f32x4_t b) {
+  const f32x2_t lo = f32x2_t{a[0], a[1]} + f32x2_t{b[0], b[1]}, hi = f32x2_t{a[2], a[3]} + f32x2_t{b[2], b[3]};
+  return f32x4_t{lo[0], lo[1], hi[0], hi[1]};
+}
 
 // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (and its L2) under the
 // round-robin dispatch, so give each XCD a contiguous run of tile ids.

@@ -261,7 +261,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
         for (int q = 0; q < 4; ++q) {
           float a = v0[q], b = v1[q];
           if (ACT_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0]; b = gq[1]; }
-          else if (EPI == HM_EPI_SILU) { a = silu(a); b = silu(b); }
+          else if (EPI == HM_EPI_SILU) { const f32x2_t sq = silu2(f32x2_t{a, b}); a = sq[0]; b = sq[1]; }
           if constexpr (EPI == HM_EPI_GELU) { a *= g.out_scale; b *= g.out_scale; }      // (x 1.0f is exact: the same bytes without a prescale)
           o[q] = (elem)a; o[4 + q] = (elem)b;
         }
@@ -343,8 +343,7 @@ __device__ __forceinline__ void epilogue(const KArgs& g, f32x4_t (&acc)[NI][MI],
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = gelu_fast(v[q]) * g.out_scale;
         } else if (EPI == HM_EPI_SILU) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+          v = silu4(v);
         } else if (RELU) {
           if (EPI == HM_EPI_ADD_RELU) {
             const typename T::vec4 idn = *(const typename T::vec4*)((const elem*)g.resid16 + (size_t)m * g.ldr16 + n);
@@ -2755,19 +2754,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(const KArgs g) {
         for (int h = 0; h < 2; ++h) {
           const f32x4_t a = acc[p][2 * np + h], bb = bv[2 * np + h];
           typename T::vec4 o;
+          f32x4_t v4 = add4(a, bb);
+          if (ACT == 1 || ACT == 3) v4 = silu4(v4);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = __fadd_rn(a[q], bb[q]);
-            if (ACT == 1) v = silu(v);
-            if (ACT == 2) v = fmaxf(v, 0.f);
-            o[q] = (elem)v;
-          }
+          for (int q = 0; q < 4; ++q) o[q] = (elem)(ACT == 2 ? fmaxf(v4[q], 0.f) : v4[q]);
           const u32x2 w = __builtin_bit_cast(u32x2, o);
           pk[h][0] = w[0]; pk[h][1] = w[1];
         }
         const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
         const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-        if (ox < g.Wout)
+        if (ox < g.Wout && (ACT != 3 || g.kser == 0x7fff))          // (ACT 3: bound diagnosis of the experiments library, nothing is stored)
           *(u32x4*)(yrow + (size_t)ox * g.ldc + (2 * np + (g4 & 1)) * 16 + (g4 >> 1) * 8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
     }
@@ -2959,13 +2955,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const KArgs g) {
       for (int h = 0; h < 2; ++h) {
         const f32x4_t a = acc[mi][h], bb = bv[h];
         typename T::vec4 o;
+        f32x4_t v4 = add4(a, bb);
+        if (ACT == 1) v4 = silu4(v4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = __fadd_rn(a[q], bb[q]);
-          if (ACT == 1) v = silu(v);
-          if (ACT == 2) v = fmaxf(v, 0.f);
-          o[q] = (elem)v;
-        }
+        for (int q = 0; q < 4; ++q) o[q] = (elem)(ACT == 2 ? fmaxf(v4[q], 0.f) : v4[q]);
         const u32x2 w = __builtin_bit_cast(u32x2, o);
         pk[h][0] = w[0]; pk[h][1] = w[1];
       }
@@ -3120,7 +3113,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2c32_kernel(const KArgs g) {
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const int ox = tx * TW + li;
-    whole = (ty + 1) * TH <= g.Hout && (tx + 1) * TW <= g.Wout;
+    whole = ACT != 3 && (ty + 1) * TH <= g.Hout && (tx + 1) * TW <= g.Wout;
     char* ytile = (char*)g.C + ((((size_t)n * g.Hout + ty * TH + 4 * pg) * g.Wout + tx * TW) * g.ldc + 32 * chh) * 2;
     f32x4_t bv[2];
 #pragma unroll
@@ -3133,19 +3126,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2c32_kernel(const KArgs g) {
       for (int h = 0; h < 2; ++h) {
         const f32x4_t a = acc[mi][h], bb = bv[h];
         typename T::vec4 o;
+        f32x4_t v4 = add4(a, bb);
+        if (ACT == 1 || ACT == 3) v4 = silu4(v4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v = __fadd_rn(a[q], bb[q]);
-          if (ACT == 1) v = silu(v);
-          if (ACT == 2) v = fmaxf(v, 0.f);
-          o[q] = (elem)v;
-        }
+        for (int q = 0; q < 4; ++q) o[q] = (elem)(ACT == 2 ? fmaxf(v4[q], 0.f) : v4[q]);
         const u32x2 w = __builtin_bit_cast(u32x2, o);
         pk[h][0] = w[0]; pk[h][1] = w[1];
       }
       const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
       const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-      if (whole || (ox < g.Wout && oy < g.Hout)) {
+      if ((whole || (ox < g.Wout && oy < g.Hout)) && (ACT != 3 || g.kser == 0x7fff)) {
         const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
         const char* yrow = ytile + (size_t)mi * g.Wout * g.ldc * 2;
         asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");   // (s_nop: see asm_store_note)
@@ -3171,6 +3161,246 @@ int launch_conv_s2c32(const KArgs& g, hipStream_t s) {
   const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, g);
   return hm_check_launch("hm_conv2d_nhwc (3x3 stride 2, 32 -> 64)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The two stem layers as ONE launch (round 4): 3(8) -> 32 at full size (3x3, stride 1) and 32 -> 64 (3x3, stride 2) behind it.
+// Apart they are the two most expensive launches of a 48-frame pass (265 + 253 us of 5.4 ms) for 5 % of its flops: the first
+// writes 755 MB, the second reads them again, and nobody else does.  With the stores removed the second layer alone runs in
+// 165 us and the first in 219 (latency of its per-lane global loads; its SiLU is not what it waits for:
+// profiles/r04_yolo_stem_bound.log).  Here the intermediate never leaves the CU: conv3x3_s2c32_kernel's two-plane halo of an
+// 8 x 16 output tile (17 x 33 pixels x 32 channels, 37 KB) is PRODUCED in LDS instead of copied from HBM --
+//   * the 19 x 35 input pixels under it (16 bytes each: 8 channels, 3 real) arrive by LDS-DMA, double-buffered, a tile ahead;
+//   * a wave takes every fourth group of 16 halo entries: per group three 32-deep MFMA steps (K = tap * 8 + ci, four taps per
+//     step, as conv3x3_direct_kernel orders it) x two channel tiles, the B fragment of a step being one ds_read_b128 per lane
+//     (the 8 channels of input pixel (hy + ky, hx + kx)); + bias, SiLU, 16-bit, and the lane's four channels go to the entry's
+//     row in the halo layout; entries outside the first layer's map (the second layer's zero padding) are written as zeros;
+//   * barrier; then the second layer exactly as conv3x3_s2c32_kernel runs it (weights in registers, nine steps of 4 reads +
+//     8 MFMAs, counted waits, lane-swap epilogue).
+// Both layers keep their K order, MFMA shape and epilogue arithmetic, and the intermediate is rounded to 16 bits as the stored
+// tensor was: the output is bit-identical to the two launches (test_stem_pair_bit_identical_to_two_launches).  ~9 % of the first
+// layer is computed twice (halo overlap of neighbouring tiles).
+struct StemPairArgs {
+  const void* X; const void* W0; const float* b0; const void* W1; const float* b1; void* C; const void* zeros;
+  int ldw0, ldw1, ldc, NB, H, Wd, Hout, Wout;
+};
+
+template <class T>
+__global__ __launch_bounds__(256, 2) void conv_stem_pair_kernel(const StemPairArgs g) {
+  using elem = typename T::elem;
+  using vec8 = typename T::vec8;
+  constexpr int TH = 8, TW = 16, HH = 2 * TH + 1, HWD = 2 * TW + 1;        // halo of first-layer outputs: 17 x 33
+  constexpr int PITCH = 17, PLANE = 296, ENTRIES = 2 * PLANE, GROUPS = ENTRIES / 16, HBUF = ENTRIES * 64;   // as conv3x3_s2c32_kernel
+  constexpr int IH = HH + 2, IW = HWD + 2, IPIX = IH * IW;                 // input pixels under the halo: 19 x 35 = 665
+  constexpr int IPIECES = (IPIX + 63) / 64, IBUF = IPIECES * 1024, NJ = (IPIECES + 3) / 4;   // 11 pieces of 64 pixels; <= 3 copies per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];              // halo HBUF | input 2 x IBUF | bias1 [64] | bias0 [32] f32
+  char* const inb = smem + HBUF;
+  float* const bias1 = (float*)(smem + HBUF + 2 * IBUF);
+  float* const bias0 = bias1 + 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g4 = lane >> 4, pg = wave >> 1, chh = wave & 1;
+  const elem* X = (const elem*)g.X;
+  // second layer's weight slice (this wave's 32 channels x 288) and the first layer's whole matrix (32 x 96) as A fragments
+  vec8 wf[9][2], wf0[3][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      wf[tap][ni] = *(const vec8*)((const elem*)g.W1 + (size_t)(32 * chh + 16 * ni + li) * g.ldw1 + 32 * tap + 8 * g4);
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      wf0[ks][nt] = *(const vec8*)((const elem*)g.W0 + (size_t)(16 * nt + li) * g.ldw0 + 32 * ks + 8 * g4);
+  if (tid < 64) bias1[tid] = g.b1[tid];
+  else if (tid < 96) bias0[tid - 64] = g.b0[tid - 64];
+
+  const int tiles_x = (g.Wout + TW - 1) / TW, tiles_y = (g.Hout + TH - 1) / TH, tpi = tiles_x * tiles_y;
+  const int ntiles = g.NB * tpi;
+  // input copy j of this wave = piece 4 j + wave = pixels 64 (4 j + wave) + lane of the 19 x 35 block, row-major, 16 B each
+  unsigned voff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int q = 64 * (4 * j + wave) + lane, iy = (q * 1873) >> 16, ix = q - iy * IW;       // q / 35 for q < 720
+    voff[j] = q < IPIX ? (unsigned)((iy * g.Wd + ix) * 16) : 0u;
+  }
+  auto issue_input = [&](int tile, int buf) {
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int y0 = 2 * ty * TH - 2, x0 = 2 * tx * TW - 2;                  // first input pixel of the block
+    char* dst = inb + buf * IBUF;
+    if (y0 >= 0 && x0 >= 0 && y0 + IH <= g.H && x0 + IW <= g.Wd) {        // the whole block lies inside the image (uniform)
+      const char* base = (const char*)(X + (((size_t)n * g.H + y0) * g.Wd + x0) * 8);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (4 * j + wave < IPIECES) glds16_hidden_s(base, voff[j], dst + (4 * j + wave) * 1024);
+    } else {
+      const elem* img = X + (size_t)n * g.H * g.Wd * 8;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (4 * j + wave < IPIECES) {
+          const int q = 64 * (4 * j + wave) + lane, iy = (q * 1873) >> 16, ix = q - iy * IW;
+          const int yy = y0 + iy, xx = x0 + ix;
+          const bool ok = q < IPIX && yy >= 0 && yy < g.H && xx >= 0 && xx < g.Wd;
+          const elem* src = ok ? img + ((size_t)yy * g.Wd + xx) * 8 : (const elem*)g.zeros;
+          glds16_hidden_v(src, dst + (4 * j + wave) * 1024);
+        }
+    }
+  };
+  // first layer: byte offset of tap (4 ks + g4) inside the input block; taps >= 9 (zero weight columns) re-read tap 8
+  unsigned tapoff[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int tap = 4 * ks + g4 < 9 ? 4 * ks + g4 : 8, ky = tap / 3, kx = tap - 3 * ky;
+    tapoff[ks] = (unsigned)((ky * IW + kx) * 16);
+  }
+  // second layer: fragment addresses as in conv3x3_s2c32_kernel (one halo buffer here)
+  unsigned faddr[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    faddr[m] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
+               (unsigned)((8 * pg * PITCH + li) * 64 + ((g4 ^ ((((li + m) >> 2) & 1) << 1)) << 4));
+  const unsigned yoff = (unsigned)((li * g.ldc + (g4 & 1) * 16 + (g4 >> 1) * 8) * 2);
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x), buf = 0;
+  bool whole = false;
+  if (tile < ntiles) issue_input(tile, 0);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) asm volatile("" : "+v"(wf[tap][ni]));      // the weight loads complete here (see conv3x3_c64_kernel)
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) asm volatile("" : "+v"(wf0[ks][nt]));
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    // this tile's input block (issued a tile ago) has landed; the previous epilogue's four stores may stay in flight
+    if (whole) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; everyone is done with the halo and the other input block
+    if (tile + (int)gridDim.x < ntiles) issue_input(tile + gridDim.x, buf ^ 1);
+    const int n = tile / tpi, rem = tile - n * tpi, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    // ---- first layer into the halo
+    {
+      const char* ib = inb + buf * IBUF;
+      const int hy0 = 2 * ty * TH - 1, hx0 = 2 * tx * TW - 1;              // first-layer coordinates of halo entry (0, 0)
+      f32x4_t bb0[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bb0[nt] = *(const f32x4_t*)(bias0 + 16 * nt + 4 * g4);
+      auto do_group = [&](int grp) {
+        const int e = 16 * grp + li, pl = e >= PLANE ? 1 : 0, r = e - pl * PLANE;
+        const int hy = (r * 241) >> 12, idx = r - hy * PITCH, hx = 2 * idx + pl;             // r / 17 for r < 600
+        const bool real = r < HH * PITCH && hx < HWD;
+        const int y = hy0 + hy, x = hx0 + hx;
+        const bool inmap = real && y >= 0 && y < g.H && x >= 0 && x < g.Wd;
+        const char* px = ib + (real ? (hy * IW + hx) * 16 : 0);
+        f32x4_t a0[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const vec8 xf = *(const vec8*)(px + tapoff[ks]);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) a0[nt] = T::mfma(wf0[ks][nt], xf, a0[nt]);
+        }
+        char* row = smem + e * 64 + 8 * (g4 & 1);
+        const int sw = ((e >> 2) & 1) << 1;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          typename T::vec4 o;
+          const f32x4_t v4 = silu4(add4(a0[nt], bb0[nt]));        // (silu2 pins the fp32 product: the 16-bit rounding is a second one, as everywhere)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (elem)v4[q];
+          typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+          u32x2 w = __builtin_bit_cast(u32x2, o);
+          w[0] = inmap ? w[0] : 0u; w[1] = inmap ? w[1] : 0u;          // outside the first layer's map: the second layer's zero padding
+          *(u32x2*)(row + (((2 * nt + (g4 >> 1)) ^ sw) << 4)) = w;
+        }
+      };
+      static_assert(GROUPS == 37, "nine groups per wave and one more for wave 0");
+#pragma unroll 3
+      for (int j = 0; j < 9; ++j) do_group(4 * j + wave);
+      if (wave == 0) do_group(36);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // the halo is complete
+    // ---- second layer out of it
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    vec8 xr[3][4];
+    auto rd = [&](auto sc) {
+      constexpr int tap = decltype(sc)::value, r = tap % 3, ky = tap / 3, kx = tap % 3;
+      vec8 (&x)[4] = xr[r];
+      unsigned (&fa)[8] = faddr;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[0]) : "v"(fa[((0 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (0 + ky) * PITCH + (kx == 2)) * 64));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[1]) : "v"(fa[((2 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (2 + ky) * PITCH + (kx == 2)) * 64));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[2]) : "v"(fa[((4 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (4 + ky) * PITCH + (kx == 2)) * 64));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[3]) : "v"(fa[((6 + ky) * PITCH + (kx == 2)) & 7]), "n"(((kx & 1) * PLANE + (6 + ky) * PITCH + (kx == 2)) * 64));
+    };
+    auto step = [&](auto sc) {
+      constexpr int tap = decltype(sc)::value, r = tap % 3;
+      if constexpr (tap + 2 < 9) rd(std::integral_constant<int, tap + 2>{});
+      vec8 (&x)[4] = xr[r];
+      constexpr int newer = (9 - 1 - tap < 2 ? 9 - 1 - tap : 2) * 4;
+      if constexpr (newer == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+      else if constexpr (newer == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = T::mfma(wf[tap][ni], xr[r][mi], acc[mi][ni]);
+    };
+    rd(std::integral_constant<int, 0>{});
+    rd(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int ox = tx * TW + li;
+    whole = (ty + 1) * TH <= g.Hout && (tx + 1) * TW <= g.Wout;
+    char* ytile = (char*)g.C + ((((size_t)n * g.Hout + ty * TH + 4 * pg) * g.Wout + tx * TW) * g.ldc + 32 * chh) * 2;
+    f32x4_t bv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) bv[h] = *(const f32x4_t*)(bias1 + 32 * chh + 16 * h + 4 * g4);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int oy = ty * TH + 4 * pg + mi;
+      unsigned pk[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4_t a = acc[mi][h], bb = bv[h];
+        typename T::vec4 o;
+        const f32x4_t v4 = silu4(add4(a, bb));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (elem)v4[q];
+        const u32x2 w = __builtin_bit_cast(u32x2, o);
+        pk[h][0] = w[0]; pk[h][1] = w[1];
+      }
+      const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+      const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+      if (whole || (ox < g.Wout && oy < g.Hout)) {
+        const u32x4 o = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        const char* yrow = ytile + (size_t)mi * g.Wout * g.ldc * 2;
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(yoff), "v"(o), "s"(yrow) : "memory");   // (s_nop: see asm_store_note)
+      }
+    }
+  }
+}
+
+template <class T>
+int launch_conv_stem_pair(const StemPairArgs& g, hipStream_t s) {
+  constexpr int LDS = 592 * 64 + 2 * 11 * 1024 + 96 * 4;
+  auto kern = conv_stem_pair_kernel<T>;
+  static HmLdsOnce lds_once;
+  if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_conv2d_stem_pair: cannot raise the dynamic LDS limit")) return rc;
+  int cus = hm_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int ntiles = g.NB * ((g.Wout + 15) / 16) * ((g.Hout + 7) / 8);
+  const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, s, g);
+  return hm_check_launch("hm_conv2d_stem_pair");
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3297,13 +3527,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_wreg_kernel(const KArgs g) {
           for (int h = 0; h < 2; ++h) {
             const f32x4_t a = acc[mi][2 * np + h], bb = bv[h];
             typename T::vec4 o;
+            f32x4_t v4 = add4(a, bb);
+            if (ACT == 1) v4 = silu4(v4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float v = __fadd_rn(a[q], bb[q]);
-              if (ACT == 1) v = silu(v);
-              if (ACT == 2) v = fmaxf(v, 0.f);
-              o[q] = (elem)v;
-            }
+            for (int q = 0; q < 4; ++q) o[q] = (elem)(ACT == 2 ? fmaxf(v4[q], 0.f) : v4[q]);
             const u32x2 w = __builtin_bit_cast(u32x2, o);
             pk[h][0] = w[0]; pk[h][1] = w[1];
           }
@@ -3484,13 +3711,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_s2c64_kernel(const KArgs g) {
         for (int h = 0; h < 2; ++h) {
           const f32x4_t a = acc[mi][h], bb = bv[h];
           typename T::vec4 o;
+          f32x4_t v4 = add4(a, bb);
+          if (ACT == 1) v4 = silu4(v4);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = __fadd_rn(a[q], bb[q]);
-            if (ACT == 1) v = silu(v);
-            if (ACT == 2) v = fmaxf(v, 0.f);
-            o[q] = (elem)v;
-          }
+          for (int q = 0; q < 4; ++q) o[q] = (elem)(ACT == 2 ? fmaxf(v4[q], 0.f) : v4[q]);
           const u32x2 w = __builtin_bit_cast(u32x2, o);
           pk[h][0] = w[0]; pk[h][1] = w[1];
         }
@@ -3566,6 +3790,14 @@ int try_conv_direct(const KArgs& g, int epilogue, hipStream_t s, bool& taken) {
   if (g.ksz != 3 || g.ldw < ((9 << g.cin_log2) + 31) / 32 * 32) return HM_OK;
   const int cin = 1 << g.cin_log2;
   taken = true;
+#ifdef HM_ABLATIONS
+  // bound diagnosis of the two stem layers (WRONG results): HM_OPT_CONV_DIRECT = 4: no activation, 5: SiLU computed, nothing stored
+  if (hm_option(HM_OPT_CONV_DIRECT) == 4 || hm_option(HM_OPT_CONV_DIRECT) == 5) {
+    const bool nostore = hm_option(HM_OPT_CONV_DIRECT) == 5;
+    if (cin == 8 && g.N == 32 && g.stride == 1) return nostore ? launch_conv_direct<T, 8, 32, 1, 3>(g, s) : launch_conv_direct<T, 8, 32, 1, 0>(g, s);
+    if (cin == 32 && g.N == 64 && g.stride == 2 && g.pad == 1) return nostore ? launch_conv_s2c32<T, 3>(g, s) : launch_conv_s2c32<T, 0>(g, s);
+  }
+#endif
   // 3x3 stride 1, 64 -> 64, when every one of the 512 persistent workgroups gets at least two 8 x 16 tiles (its weight slice is
   // loaded into registers once per workgroup): 16 frames, 192 x 320: 138 -> 79 us; 96 x 160 (3.75 tiles each): 40.4 -> 30.5 us;
   // 48 x 80 (480 tiles, not taken): 16.8 -> 18.2 us.  The two kernels agree to the bit, so the choice may depend on the batch.
@@ -3724,7 +3956,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float u = __fadd_rn(s0[q], a0[q]), v = __fadd_rn(s1[q], a1[q]);          // acc + bias, then the activation: as the fused epilogue rounds
-    if (ACT == 1) { u = silu(u); v = silu(v); }
+    if (ACT == 1) { const f32x2_t sq = silu2(f32x2_t{u, v}); u = sq[0]; v = sq[1]; }
     if (ACT == 2) { u = fmaxf(u, 0.f); v = fmaxf(v, 0.f); }
     o[q] = (typename T::elem)u; o[4 + q] = (typename T::elem)v;
   }
@@ -3966,4 +4198,28 @@ extern "C" int hm_conv2d_nhwc(const hm_conv_args* a, void* stream_) {
   if (c.dtype == HM_DTYPE_BF16) return launch_conv<TBf16>(k, epi, c.splitk_ws, c.splitk_ws_bytes, stream);
   if (c.dtype == HM_DTYPE_F16) return launch_conv<TF16>(k, epi, c.splitk_ws, c.splitk_ws_bytes, stream);
   return hm_set_error(HM_ERR_ARG, "hm_conv2d_nhwc: bad dtype");
+}
+
+extern "C" int hm_conv2d_stem_pair(const hm_conv_args* first, const hm_conv_args* second, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!first || !second) return hm_set_error(HM_ERR_ARG, "hm_conv2d_stem_pair: null args");
+  const hm_conv_args &a = *first, &b = *second;
+  const bool fused = hm_option(HM_OPT_CONV_STEM_PAIR) == 0 && hm_option(HM_OPT_CONV_DIRECT) != 1 &&
+      a.X && a.W && a.Y && a.bias && a.zeros && b.W && b.Y && b.bias && a.dtype == b.dtype && (a.dtype == HM_DTYPE_F16 || a.dtype == HM_DTYPE_BF16) &&
+      a.ksize == 3 && a.stride == 1 && a.Cin == 8 && a.ldx == 8 && a.Cout == 32 && a.ldy == 32 && a.act == 1 && !a.out_f32 && !a.resid && a.Kpad >= 96 && a.Kpad % 8 == 0 &&
+      b.X == a.Y && b.ksize == 3 && b.stride == 2 && b.Cin == 32 && b.ldx == 32 && b.Cout == 64 && b.act == 1 && !b.out_f32 && !b.resid && b.Kpad >= 288 && b.Kpad % 8 == 0 &&
+      b.N == a.N && b.H == a.H && b.W_in == a.W_in && a.N > 0 && a.H > 0 && a.W_in > 0 && b.ldy % 8 == 0 && b.ldy >= 64 &&
+      ((((uintptr_t)a.X | (uintptr_t)a.W | (uintptr_t)b.W | (uintptr_t)a.bias | (uintptr_t)b.bias | (uintptr_t)b.Y | (uintptr_t)a.zeros) & 15) == 0) &&
+      (size_t)20 * a.W_in * 16 < (1ull << 31) && (size_t)16 * ((a.W_in - 1) / 2 + 1) * b.ldy * 2 < (1ull << 31);
+  if (!fused) {
+    const int rc = hm_conv2d_nhwc(first, stream);
+    return rc != HM_OK ? rc : hm_conv2d_nhwc(second, stream);
+  }
+  StemPairArgs g{};
+  g.X = a.X; g.W0 = a.W; g.b0 = a.bias; g.W1 = b.W; g.b1 = b.bias; g.C = b.Y; g.zeros = a.zeros;
+  g.ldw0 = a.Kpad; g.ldw1 = b.Kpad; g.ldc = b.ldy; g.NB = a.N; g.H = a.H; g.Wd = a.W_in;
+  g.Hout = (a.H - 1) / 2 + 1; g.Wout = (a.W_in - 1) / 2 + 1;
+  // one profile record for the launch: the second layer's rows and columns, K = 288 + 4 * 72 / 2: 2 M N K is the flop count of both layers
+  HmProfScope prof(HM_K_CONV, 32, g.NB * g.Hout * g.Wout, 64, 288 + 144, stream);
+  return a.dtype == HM_DTYPE_BF16 ? launch_conv_stem_pair<TBf16>(g, stream) : launch_conv_stem_pair<TF16>(g, stream);
 }

@@ -463,6 +463,11 @@ extern "C" int hm_yolo_run(const hm_yolo_op* ops, int n_ops, void* stream) {
     const hm_conv_args& c = o.conv;
     int rc;
     if (o.kind == HM_OP_CONV) rc = hm_conv2d_nhwc(&c, stream);
+    else if (o.kind == HM_OP_CONV_PAIR) {
+      if (i + 1 >= n_ops || ops[i + 1].kind != HM_OP_CONV) return hm_set_error(HM_ERR_ARG, "hm_yolo_run: HM_OP_CONV_PAIR needs a convolution behind it");
+      rc = hm_conv2d_stem_pair(&c, &ops[i + 1].conv, stream);
+      ++i;
+    }
     else if (o.kind == HM_OP_MAXPOOL) rc = hm_maxpool_nhwc(c.X, c.ldx, c.Y, c.ldy, c.N, c.H, c.W_in, c.Cin, c.ksize, c.stride, o.pool_pad, c.dtype, stream);
     else if (o.kind == HM_OP_UPSAMPLE2X) rc = hm_upsample2x_nhwc(c.X, c.ldx, c.Y, c.ldy, c.N, c.H, c.W_in, c.Cin, c.dtype, stream);
     else return hm_set_error(HM_ERR_ARG, "hm_yolo_run: unknown op kind");

@@ -538,6 +538,8 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             taken.append(got[0])
             return got[1]
         im = _imread_bgr(path, alloc, raw)
+        if trace is not None and index % 8 == 7:
+            mark(f"decoded file {index}")
         if im is not None and not taken:                              # not decoded in place (PIL path): one copy into the slot
             got = ring.slot(index, im.shape)
             if got is not None:
@@ -564,6 +566,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
                         d[j].copy_(t, non_blocking=True)
                 ev = new_event()
                 ev.record(dstream)
+                mark(f"det_upload_enqueued {len(items)}")
                 for fi, _, _, _ in items:
                     ring.events[fi % ring.n] = ev
                 # frames the decoders left bottom-up (raw BMP rows, one read per file) are turned on the device: one flip of the
@@ -737,6 +740,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             if frames_left and len(det_jobs) < 2 and expected < 3 * H:
                 items = next_items(first_pass if passes == 0 else big_pass)
                 if items:
+                    mark(f"det_items_ready {len(items)}")
                     passes += 1
                     try:
                         det_jobs.append(det_enqueue(items[0][0], items))

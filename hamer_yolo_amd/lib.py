@@ -21,14 +21,14 @@ HM_VERSION = 400      # include/hamer_hip.h: load() refuses a library built from
 OPTION_NAMES = ("HM_OPT_PX_GRID", "HM_OPT_FP8P_GRID", "HM_OPT_FP8_ONE_TILE", "HM_OPT_FP8P_RESID", "HM_OPT_TOME_NO_SPLITK",
                 "HM_OPT_TOME_SCALAR_ATTENTION", "HM_OPT_RESID_IN_EPILOGUE", "HM_OPT_CONV_TILE", "HM_OPT_CONV_SPLITK",
                 "HM_OPT_PX_LDS_EPILOGUE", "HM_OPT_CONV_DIRECT", "HM_OPT_GEMM_TILE_RULE", "HM_OPT_CONV_KGROUPS",
-                "HM_OPT_CONV_GENERAL_LOADER")
+                "HM_OPT_CONV_GENERAL_LOADER", "HM_OPT_CONV_STEM_PAIR")
 globals().update({_n: _i for _i, _n in enumerate(OPTION_NAMES)})
 
 EXPORTS = [
     "hm_version", "hm_last_error_string", "hm_gemm", "hm_layernorm", "hm_vit_attention", "hm_patch_im2col",
     "hm_linear_f32", "hm_broadcast_rows", "hm_cross_attention", "hm_mano_forward", "hm_crop_box_from_bbox",
     "hm_crop_batch", "hm_hamer_workspace_bytes", "hm_hamer_forward", "hm_prof_begin", "hm_prof_collect", "hm_prof_end",
-    "hm_conv2d_nhwc", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
+    "hm_conv2d_nhwc", "hm_conv2d_stem_pair", "hm_maxpool_nhwc", "hm_upsample2x_nhwc", "hm_letterbox_plan_make", "hm_letterbox_tables",
     "hm_letterbox", "hm_yolo_decode", "hm_nms_workspace_bytes", "hm_yolo_nms", "hm_yolo_run", "hm_gemm_set_variant", "hm_gemm_set_group_m", "hm_ln_finalize", "hm_layernorm_accum", "hm_gemm_fp8", "hm_layernorm_mx8", "hm_vit_attention_mx8", "hm_nchw3_to_nhwc8", "hm_gap_linear",
     "hm_tome_index_bytes", "hm_tome_attention", "hm_tome_merge", "hm_set_option", "hm_get_option", "hm_tome_merge_metric", "hm_conv_splitk_bytes", "hm_yolo_decode_batch", "hm_letterbox_batch",
     "hm_option_count", "hm_gemm_px_grid", "hm_absmax16",
@@ -166,6 +166,7 @@ def load() -> C.CDLL:
     lib.hm_absmax16.argtypes = [vp, i, i, i, i, i, vp, vp]
     lib.hm_conv2d_nhwc.argtypes = [C.POINTER(ConvArgs), vp]
     lib.hm_conv_splitk_bytes.argtypes = [C.POINTER(ConvArgs)]
+    lib.hm_conv2d_stem_pair.argtypes = [C.POINTER(ConvArgs), C.POINTER(ConvArgs), vp]
     lib.hm_conv_splitk_bytes.restype = C.c_size_t
     lib.hm_maxpool_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, i, i, i, vp]
     lib.hm_upsample2x_nhwc.argtypes = [vp, i, vp, i, i, i, i, i, i, vp]

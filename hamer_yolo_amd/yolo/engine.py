@@ -72,6 +72,7 @@ class YoloEngine:
         self._stacked: Dict[Tuple[str, str], Tuple[torch.Tensor, torch.Tensor]] = {}   # stacked weights of fused 1x1 pairs
         self.fuse_pairs = True        # E-ELAN cv1 / cv2 as one launch (round 3); False: one launch per convolution, as the reference's graph
         self.split_k = True           # give the library split-K scratch for the small maps of the neck (round 3)
+        self.fuse_stem = True         # Conv 0 + Conv 1 as one launch, the 32-channel full-size map never written (round 4); False: two launches
 
     # ------------------------------------------------------------------ planning
     def _plan(self, H: int, W: int, nb: int = 1) -> dict:
@@ -146,13 +147,20 @@ class YoloEngine:
         ops: List[L.YoloOp] = []
         pending = []                                           # convolutions in launch order, before pair fusion
 
+        readers: Dict[int, int] = {}                           # layer -> how many layers read its output
+        for srcs, _, _ in layers:
+            for s_ in srcs:
+                if s_ >= 0:
+                    readers[s_] = readers.get(s_, 0) + 1
+        sole = set()                                           # output pointers with exactly one reader
+
         def conv(name, xptr, ldx, h, w, yptr, ldy, act=1, out_f32=0):
             pending.append(("conv", name, xptr, ldx, h, w, yptr, ldy, act, out_f32))
 
-        def emit_conv(wt, bs, cin, k, s, co, xptr, ldx, h, w, yptr, ldy, act, out_f32):
+        def emit_conv(wt, bs, cin, k, s, co, xptr, ldx, h, w, yptr, ldy, act, out_f32, kind=0):
             a = L.ConvArgs(xptr, wt.data_ptr(), yptr, bs.data_ptr(), self.zeros.data_ptr(), nb, h, w, cin, co, k, s, ldx, ldy,
                            wt.shape[1], act, out_f32, self.dt, None, 0, None, 0)
-            ops.append(L.YoloOp(0, 0, a))
+            ops.append(L.YoloOp(kind, 0, a))
 
         def flush():
             """Emit the pending convolutions.  Two consecutive 1x1 convolutions that read the SAME tensor and write ADJACENT
@@ -163,6 +171,16 @@ class YoloEngine:
             while i < len(pending):
                 _, name, xptr, ldx, h, w, yptr, ldy, act, out_f32 = pending[i]
                 wt, bs, cin, k, s, co = self.w[name]
+                if self.fuse_stem and i + 1 < len(pending) and yptr in sole and (cin, k, s, co, ldx, ldy, act, out_f32) == (8, 3, 1, 32, 8, 32, 1, 0):
+                    # Conv 0 -> Conv 1 (yolov7.yaml backbone: [-1, 1, Conv, [32, 3, 1]], [-1, 1, Conv, [64, 3, 2]]): nobody but the second
+                    # reads the first's output -- HM_OP_CONV_PAIR: one launch, the intermediate is not written (hm_conv2d_stem_pair)
+                    _, name2, xptr2, ldx2, h2, w2, yptr2, ldy2, act2, out2 = pending[i + 1]
+                    wt2, bs2, cin2, k2, s2, co2 = self.w[name2]
+                    if (xptr2, ldx2, h2, w2, cin2, k2, s2, co2, act2, out2) == (yptr, ldy, h, w, 32, 3, 2, 64, 1, 0):
+                        emit_conv(wt, bs, cin, k, s, co, xptr, ldx, h, w, yptr, ldy, act, out_f32, kind=3)
+                        emit_conv(wt2, bs2, cin2, k2, s2, co2, xptr2, ldx2, h2, w2, yptr2, ldy2, act2, out2)
+                        i += 2
+                        continue
                 if self.fuse_pairs and i + 1 < len(pending):
                     _, name2, xptr2, ldx2, h2, w2, yptr2, ldy2, act2, out2 = pending[i + 1]
                     wt2, bs2, cin2, k2, s2, co2 = self.w[name2]
@@ -195,6 +213,8 @@ class YoloEngine:
             h, w = (lp.out_h, lp.out_w) if s0 == IMG else hw[s0]
             if kind == "conv":
                 yptr, ldy = loc(i)
+                if readers.get(i, 0) == 1 and home[i][0] == i:
+                    sole.add(yptr)
                 conv(f"model.{i}.conv", xptr, ldx, h, w, yptr, ldy)
             elif kind == "repconv":
                 yptr, ldy = loc(i)

@@ -103,7 +103,8 @@ enum {
   HM_OPT_GEMM_TILE_RULE = 11,       /* tuning: 1 = round 2's GEMM tile rule (256 x 256 only from 85 % full rounds), 0 = the rate model */
   HM_OPT_CONV_KGROUPS = 12,         /* tuning: 1 = no K groups inside a convolution workgroup (small maps), 0 = automatic */
   HM_OPT_CONV_GENERAL_LOADER = 13,  /* tuning / tests: 1 = the implicit-GEMM convolution takes its general loader (per-lane tap arithmetic every K-step) even where the lean one applies (Cin % 64 == 0); 0 = automatic.  Same bytes either way */
-  HM_OPT_COUNT = 14
+  HM_OPT_CONV_STEM_PAIR = 14,       /* tuning / tests: 1 = hm_conv2d_stem_pair (and HM_OP_CONV_PAIR of hm_yolo_run) always runs its two convolutions as two launches; 0 = one launch where the fused kernel applies.  Same bytes either way */
+  HM_OPT_COUNT = 15
 };
 int hm_set_option(int key, int value);
 int hm_get_option(int key);
@@ -356,6 +357,13 @@ typedef struct hm_conv_args {
 int hm_conv2d_nhwc(const hm_conv_args* args, void* stream);
 /* bytes of splitk_ws this convolution would use (0: it is never split) */
 size_t hm_conv_splitk_bytes(const hm_conv_args* args);
+/* Two consecutive convolutions of which the second is the ONLY reader of the first's output: Conv 0 and Conv 1 of yolov7.yaml
+ * (yolo.py Model.forward_once walks them one after the other; 3 -> 32, k3 s1, then 32 -> 64, k3 s2, both SiLU).  Where the fused
+ * kernel applies (first: Cin 8 (3 real), ldx 8, Cout 32, k3 s1, SiLU; second: X == first.Y, ldx == first.ldy == 32, Cout 64, k3 s2,
+ * SiLU, ldy % 8 == 0, Y 16-byte aligned; one dtype) both run as ONE launch and first->Y is NOT written (the intermediate stays in
+ * LDS; the result is bit-identical to the two launches); anywhere else, or with HM_OPT_CONV_STEM_PAIR = 1, this is
+ * hm_conv2d_nhwc(first) followed by hm_conv2d_nhwc(second). */
+int hm_conv2d_stem_pair(const hm_conv_args* first, const hm_conv_args* second, void* stream);
 
 /* nn.MaxPool2d(k, stride, pad) on NHWC 16-bit (MP common.py:34-40: k=2,s=2; SPPCSPC common.py:275:
  * k=5/9/13, s=1, pad k/2 -- the 9 and 13 windows are cascades of the 5 window). C % 8 == 0. */
@@ -415,7 +423,8 @@ int hm_yolo_nms(const float* pred, int n, int nc, float conf_thres, float iou_th
 
 /* One enqueue for a whole planned graph (Model.forward_once, yolo.py:609-639): the host planner
  * (hamer_yolo_amd/yolo/engine.py) turns the layer list into this op array once per input size. */
-enum { HM_OP_CONV = 0, HM_OP_MAXPOOL = 1, HM_OP_UPSAMPLE2X = 2 };
+enum { HM_OP_CONV = 0, HM_OP_MAXPOOL = 1, HM_OP_UPSAMPLE2X = 2,
+       HM_OP_CONV_PAIR = 3 /* this op's conv and the NEXT op's (kind HM_OP_CONV) through hm_conv2d_stem_pair; the next op is consumed */ };
 typedef struct hm_yolo_op {
   int kind;
   int pool_pad;       /* HM_OP_MAXPOOL: padding; ksize/stride/N/H/W_in/Cin(=C)/X/Y/ldx/ldy/dtype come from conv */

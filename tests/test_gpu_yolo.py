@@ -328,6 +328,71 @@ def test_conv_split_k_exact_and_close(dt):
     np.testing.assert_allclose(four.numpy(), one.numpy(), atol=1e-4, rtol=2 * ulp)     # one 16-bit ulp: the fp32 sums differ in the last bits
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,H,W", [(2, 64, 96), (1, 50, 70), (3, 33, 47), (1, 384, 640), (5, 16, 32)])
+def test_stem_pair_bit_identical_to_two_launches(n, H, W, dt):
+    """hm_conv2d_stem_pair: Conv 0 (3(8) -> 32, k3 s1) and Conv 1 (32 -> 64, k3 s2) of the detector as ONE launch whose
+    intermediate lives in LDS.  Both layers keep their K order, MFMA shape and epilogue arithmetic and the intermediate is
+    rounded to 16 bits as the stored tensor would be, so the output must equal the two launches (HM_OPT_CONV_STEM_PAIR = 1)
+    BIT FOR BIT -- interior tiles, tiles on every border, odd sizes whose last tiles overhang the map, several frames -- and
+    the first layer's output buffer must stay untouched."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(n * 1000 + H)
+    x = torch.zeros(n, H, W, 8, dtype=dt)
+    x[..., :3] = torch.rand(n, H, W, 3, generator=g).to(dt)
+    w0 = torch.zeros(32, 128)
+    w0[:, :72] = ((torch.rand(32, 3, 3, 8, generator=g) - 0.5) * 0.8 * (torch.arange(8) < 3)).reshape(32, 72)
+    w1 = torch.zeros(64, 320)
+    w1[:, :288] = ((torch.rand(64, 288, generator=g) - 0.5) * 0.25)
+    b0, b1 = (torch.rand(32, generator=g) - 0.5), (torch.rand(64, generator=g) - 0.5)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xd, w0d, w1d, b0d, b1d = x.to(DEV), w0.to(dt).to(DEV), w1.to(dt).to(DEV), b0.to(DEV), b1.to(DEV)
+    zeros = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    code = L.HM_DTYPE_BF16 if dt == torch.bfloat16 else L.HM_DTYPE_F16
+    outs = []
+    try:
+        for two in (1, 0):
+            mid = torch.full((n, H, W, 32), 7.0, dtype=dt, device=DEV)
+            y = torch.full((n, Ho, Wo, 64 + 8), -3.0, dtype=dt, device=DEV)       # (a wider buffer: ldy 72, channel slice at +8)
+            a = L.ConvArgs(xd.data_ptr(), w0d.data_ptr(), mid.data_ptr(), b0d.data_ptr(), zeros.data_ptr(), n, H, W, 8, 32, 3, 1, 8, 32, 128, 1, 0, code, None, 0, None, 0)
+            b = L.ConvArgs(mid.data_ptr(), w1d.data_ptr(), y.data_ptr() + 16, b1d.data_ptr(), zeros.data_ptr(), n, H, W, 32, 64, 3, 2, 32, 72, 320, 1, 0, code, None, 0, None, 0)
+            L.check(lib.hm_set_option(L.HM_OPT_CONV_STEM_PAIR, two))
+            L.check(lib.hm_conv2d_stem_pair(C.byref(a), C.byref(b), L.current_stream()), "hm_conv2d_stem_pair")
+            torch.cuda.synchronize()
+            outs.append((y.cpu(), mid.cpu()))
+    finally:
+        L.check(lib.hm_set_option(L.HM_OPT_CONV_STEM_PAIR, 0))
+    (y2, mid2), (y1, mid1) = outs
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16))
+    assert (y1[..., :8] == -3.0).all()                               # the neighbouring channel slice is untouched
+    assert (mid1 == 7.0).all() and not (mid2 == 7.0).all()           # one launch: the intermediate is never written
+    assert y1[..., 8:].float().abs().max() > 0.05
+
+
+def test_stem_fusion_does_not_change_the_network():
+    """The engine with Conv 0 + Conv 1 as one launch (HM_OP_CONV_PAIR, the default) against the engine that launches them
+    apart: Conv 1's output and the head's raw logits are bit-identical, so every per-layer statement of
+    test_every_layer_vs_oracle_on_the_gpus_own_inputs (which needs Conv 0's output in memory and therefore runs the two
+    launches) holds for the fused network as well; two frames in one pass too."""
+    sd = synth.yolo_state_dict(seed=0, nc=3)
+    frames = [synth.frame_u8(540, 960, seed=5).to(DEV), synth.frame_u8(540, 960, seed=6).to(DEV)]
+    outs = {}
+    for fused_stem in (False, True):
+        e = YoloEngine(sd, nc=3, device=DEV)
+        e.fuse_stem = fused_stem
+        p = e.forward(frames[0])
+        torch.cuda.synchronize()
+        one = (e.layer_output(p, 0), e.layer_output(p, 1), [r[0].clone().cpu() for r in p["raws"]], p["n_ops"], [int(o.kind) for o in p["ops"]][:2])
+        p2 = e.forward(frames)
+        torch.cuda.synchronize()
+        outs[fused_stem] = one + ([r[0].clone().cpu() for r in p2["raws"]],)
+    assert outs[True][4] == [3, 0] and outs[False][4] == [0, 0] and outs[True][3] == outs[False][3]
+    assert float(outs[True][0].abs().max()) == 0.0 and float(outs[False][0].abs().max()) > 0.0      # Conv 0's map is not written
+    assert torch.equal(outs[True][1], outs[False][1])
+    for a, b_ in zip(outs[True][2] + outs[True][5], outs[False][2] + outs[False][5]):
+        assert torch.equal(a, b_)
+
+
 def test_yolo_pair_fusion_and_split_k_do_not_change_the_network():
     """E-ELAN cv1 / cv2 (two 1x1 convolutions of one input, adjacent slices of the block's Concat) run as one launch with
     stacked weight rows: every output channel is the same dot product in the same K order, so every layer output of the
@@ -400,7 +465,7 @@ def _fused():
     return layers, fuse.fuse_state_dict(synth.yolo_state_dict(seed=0, nc=3), arch.conv_specs(layers, 3, 3))
 
 
-def test_every_layer_vs_oracle_on_the_gpus_own_inputs(engine):
+def test_every_layer_vs_oracle_on_the_gpus_own_inputs():
     """Teacher-forced, layer by layer: each of the 105 layers + the detect head is recomputed by the oracle (emu="fp16": half
     weights / activations, fp32 accumulate -- the reference's GPU branch, detector.py:110-112) FROM THE GPU'S OWN INPUT
     TENSORS of that layer and compared with the GPU's output of that layer.  What is left between the two is the fp32
@@ -409,7 +474,9 @@ def test_every_layer_vs_oracle_on_the_gpus_own_inputs(engine):
     through 105 layers of |x| <= 15 activations to ~2e-3 mean / 6e-2 max on the logits -- the floor for ANY two half
     implementations with different summation orders -- so the whole-network bounds below are necessarily looser.)"""
     frame = synth.frame_u8(540, 960, seed=5)
-    p = engine.forward(frame.to(DEV))
+    engine = YoloEngine(synth.yolo_state_dict(seed=0, nc=3), nc=3, device=DEV)
+    engine.fuse_stem = False          # (every layer's output in memory; the fused stem is tied to this run bit for bit by
+    p = engine.forward(frame.to(DEV))  #  test_stem_fusion_does_not_change_the_network)
     torch.cuda.synchronize()
     layers, fused = _fused()
     lp = p["lp"]

@@ -5,6 +5,8 @@ Usage: python tools/prof_yolo.py [frames=16] [reps=3]      (rocprofv3 --kernel-t
 import os, sys, collections, torch
 sys.path.insert(0, ".")
 from hamer_yolo_amd import synth, lib as L
+if os.environ.get("ABLATION_LIB"):     # experiments library (python -m hamer_yolo_amd.build --ablations): CONV_DIRECT=4 / 5 = the two stem layers
+    L.LIB_PATH = L.LIB_PATH.replace(".so", "_abl.so")   # without their activation / without their stores (WRONG results, bound diagnosis only)
 from hamer_yolo_amd.yolo.engine import YoloEngine
 import os as _os, sys as _sys
 _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__))))
@@ -15,6 +17,7 @@ REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 eng = YoloEngine(synth.yolo_state_dict(seed=0, nc=3), nc=3, device="cuda")
 eng.fuse_pairs = os.environ.get("FUSE", "1") == "1"
 eng.split_k = os.environ.get("SPLITK_WS", "1") == "1"
+eng.fuse_stem = os.environ.get("FUSE_STEM", "1") == "1"     # 0: Conv 0 and Conv 1 as two launches
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_TILE, int(os.environ.get("CONV_TILE", 0))))       # 1..6: force one tile for every layer
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_SPLITK, int(os.environ.get("CONV_SPLITK", 0))))   # 1: never split
 L.check(L.load().hm_set_option(L.HM_OPT_CONV_KGROUPS, int(os.environ.get("CONV_KGROUPS", 0))))   # 1: no K groups inside a workgroup
