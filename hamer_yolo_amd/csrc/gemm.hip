@@ -1312,7 +1312,7 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 // TWEAK (experiments): 1 = read order X0 W0 X1 X2 X3 W1.. (first MFMA behind two reads), 2 = no s_setprio around the MFMA runs.
 template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false, bool LEAN = true, bool XFIRST = true, bool R1EARLY = false, int TWEAK = 0>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
-  static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU, "16-bit store epilogues only");
+  static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU, "16-bit store epilogues only");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
   constexpr int TILE_BYTES = 256 * ROWB;                               // 32 KB
   constexpr int XRING = 0, WRING = 3 * TILE_BYTES;
@@ -1564,6 +1564,10 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
               const f32x2_t g0 = gelu_fast2(f32x2_t{v0, v1}), g1 = gelu_fast2(f32x2_t{v2, v3});
               v0 = g0[0] * g.out_scale; v1 = g0[1] * g.out_scale; v2 = g1[0] * g.out_scale; v3 = g1[1] * g.out_scale;
             }
+            if constexpr (EPI == HM_EPI_SILU) {                  // (1x1 convolutions of the detector: launch_conv)
+              const f32x2_t g0 = silu2(f32x2_t{v0, v1}), g1 = silu2(f32x2_t{v2, v3});
+              v0 = g0[0]; v1 = g0[1]; v2 = g1[0]; v3 = g1[1];
+            }
             typename T::vec4 o;
             o[0] = (elem)v0; o[1] = (elem)v1; o[2] = (elem)v2; o[3] = (elem)v3;
             const u32x2 w = __builtin_bit_cast(u32x2, o);
@@ -1597,6 +1601,7 @@ __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
           for (int q = 0; q < 4; ++q) {
             float a = __fadd_rn(v0[q], b0[q]), b = __fadd_rn(v1[q], b1[q]);           // as the one-tile kernels round
             if constexpr (EPI == HM_EPI_GELU) { const f32x2_t gq = gelu_fast2(f32x2_t{a, b}); a = gq[0] * g.out_scale; b = gq[1] * g.out_scale; }
+            if constexpr (EPI == HM_EPI_SILU) { const f32x2_t sq = silu2(f32x2_t{a, b}); a = sq[0]; b = sq[1]; }
             o[q] = (elem)a; o[4 + q] = (elem)b;
           }
           *(vec8*)((elem*)g.C + (size_t)(mb + half * 32 + row) * g.ldc + nb + cg * 32 + 8 * j) = o;
@@ -1978,7 +1983,7 @@ int launch_px(const KArgs& g, hipStream_t s) {
   // and 3 % slower for the plain store (qkv 119.8 vs 116.4, kv 177.2 vs 170.9) -- so each epilogue takes its faster form.
   // HM_OPT_PX_LDS_EPILOGUE: 0 = that choice, 1 = always through LDS, 2 = always lane swaps.
   const int form = hm_option(HM_OPT_PX_LDS_EPILOGUE);
-  const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || EPI != HM_EPI_GELU));
+  const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || (EPI != HM_EPI_GELU && EPI != HM_EPI_SILU)));
   if (PIPE == 4 && !g.ln_stats) return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 (stamps) needs a device buffer of 6 x 8 bytes per workgroup in ln_stats");   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
 #ifdef HM_ABLATIONS
   auto kern = PIPE == 9 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, false, 2> : gemm_px_kernel<T, EPI, true, false, false, true, true, false, 2>)
@@ -3193,10 +3198,11 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pair_kernel(const StemPairAr
   constexpr int PITCH = 17, PLANE = 296, ENTRIES = 2 * PLANE, GROUPS = ENTRIES / 16, HBUF = ENTRIES * 64;   // as conv3x3_s2c32_kernel
   constexpr int IH = HH + 2, IW = HWD + 2, IPIX = IH * IW;                 // input pixels under the halo: 19 x 35 = 665
   constexpr int IPIECES = (IPIX + 63) / 64, IBUF = IPIECES * 1024, NJ = (IPIECES + 3) / 4;   // 11 pieces of 64 pixels; <= 3 copies per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];              // halo HBUF | input 2 x IBUF | bias1 [64] | bias0 [32] f32
+  extern __shared__ __attribute__((aligned(16))) char smem[];              // halo HBUF | input 2 x IBUF | bias1 [64] | bias0 [32] f32 | entry table [592] x 8 B
   char* const inb = smem + HBUF;
   float* const bias1 = (float*)(smem + HBUF + 2 * IBUF);
   float* const bias0 = bias1 + 64;
+  char* const etab = (char*)(bias0 + 32);               // per halo entry: where its pixel sits in the input block, (hy, hx), flags
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, g4 = lane >> 4, pg = wave >> 1, chh = wave & 1;
@@ -3215,6 +3221,15 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pair_kernel(const StemPairAr
       wf0[ks][nt] = *(const vec8*)((const elem*)g.W0 + (size_t)(16 * nt + li) * g.ldw0 + 32 * ks + 8 * g4);
   if (tid < 64) bias1[tid] = g.b1[tid];
   else if (tid < 96) bias0[tid - 64] = g.b0[tid - 64];
+  for (int e = tid; e < ENTRIES; e += 256) {            // tile-invariant geometry of the halo entries (conv3x3_s2c32_kernel's two planes)
+    const int pl = e >= PLANE ? 1 : 0, r = e - pl * PLANE, hy = r / PITCH, idx = r - hy * PITCH, hx = 2 * idx + pl;
+    const bool real = r < HH * PITCH && hx < HWD;
+    uint2 tb;
+    tb.x = real ? (unsigned)((hy * IW + hx) * 16) : 0u;
+    tb.y = real ? (unsigned)(hy | (hx << 8) | 0x10000 | (((e >> 2) & 1) << 24)) : (unsigned)(((e >> 2) & 1) << 24);
+    *(uint2*)(etab + e * 8) = tb;
+  }
+  const unsigned wlane = (unsigned)(((g4 >> 1) << 4) + 8 * (g4 & 1));   // this lane's place in an entry's 64-byte row: chunk g4 >> 1 (+ 2 nt), half g4 & 1
 
   const int tiles_x = (g.Wout + TW - 1) / TW, tiles_y = (g.Hout + TH - 1) / TH, tpi = tiles_x * tiles_y;
   const int ntiles = g.NB * tpi;
@@ -3287,38 +3302,74 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pair_kernel(const StemPairAr
       f32x4_t bb0[2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) bb0[nt] = *(const f32x4_t*)(bias0 + 16 * nt + 4 * g4);
-      auto do_group = [&](int grp) {
-        const int e = 16 * grp + li, pl = e >= PLANE ? 1 : 0, r = e - pl * PLANE;
-        const int hy = (r * 241) >> 12, idx = r - hy * PITCH, hx = 2 * idx + pl;             // r / 17 for r < 600
-        const bool real = r < HH * PITCH && hx < HWD;
-        const int y = hy0 + hy, x = hx0 + hx;
-        const bool inmap = real && y >= 0 && y < g.H && x >= 0 && x < g.Wd;
-        const char* px = ib + (real ? (hy * IW + hx) * 16 : 0);
-        f32x4_t a0[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+      // NG groups at a time, in phases: all their fragment reads, then the MFMAs (2 NG independent chains), then the SiLUs, then
+      // the stores -- written group by group hipcc keeps every group's reads behind the previous group's stores (both are LDS)
+      // and the wave sits out a read latency, an MFMA chain and a SiLU chain per group.  An entry's geometry comes from the
+      // table (one ds_read_b64 instead of ~20 vector instructions: the kernel is bound by vector issue, profiles/r04_pmc_stem_pair.json);
+      // EDGE: the tile touches the map's border -- only there can an entry lie outside the map and must be written as zero.
+      auto do_groups = [&](auto ngc, auto edgec, int grp0) {
+        constexpr int NG = decltype(ngc)::value;
+        constexpr bool EDGE = decltype(edgec)::value;
+        unsigned wr[NG]; bool inmap[NG];
+        vec8 xf[NG][3];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-          const vec8 xf = *(const vec8*)(px + tapoff[ks]);
+        for (int u = 0; u < NG; ++u) {
+          const int e = 16 * (grp0 + 4 * u) + li;
+          const uint2 tb = *(const uint2*)(etab + e * 8);               // x: byte offset of the entry's pixel in the input block | y: hy | hx << 8 | real << 16
+          wr[u] = ((unsigned)(e * 64) + wlane) ^ ((tb.y >> 19) & 32u);     // halo row + this lane's place; the swizzle bit rides in tb.y bit 24
+          if constexpr (EDGE) {
+            const int hy = tb.y & 255, hx = (tb.y >> 8) & 255;
+            inmap[u] = (tb.y & 0x10000u) != 0 && (unsigned)(hy0 + hy) < (unsigned)g.H && (unsigned)(hx0 + hx) < (unsigned)g.Wd;
+          }
+          const char* px = ib + tb.x;
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) a0[nt] = T::mfma(wf0[ks][nt], xf, a0[nt]);
+          for (int ks = 0; ks < 3; ++ks) xf[u][ks] = *(const vec8*)(px + tapoff[ks]);
         }
-        char* row = smem + e * 64 + 8 * (g4 & 1);
-        const int sw = ((e >> 2) & 1) << 1;
+        f32x4_t a0[NG][2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          typename T::vec4 o;
-          const f32x4_t v4 = silu4(add4(a0[nt], bb0[nt]));        // (silu2 pins the fp32 product: the 16-bit rounding is a second one, as everywhere)
+        for (int u = 0; u < NG; ++u)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (elem)v4[q];
-          typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-          u32x2 w = __builtin_bit_cast(u32x2, o);
-          w[0] = inmap ? w[0] : 0u; w[1] = inmap ? w[1] : 0u;          // outside the first layer's map: the second layer's zero padding
-          *(u32x2*)(row + (((2 * nt + (g4 >> 1)) ^ sw) << 4)) = w;
+          for (int nt = 0; nt < 2; ++nt) a0[u][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+          for (int u = 0; u < NG; ++u)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) a0[u][nt] = T::mfma(wf0[ks][nt], xf[u][ks], a0[u][nt]);
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        u32x2 w[NG][2];
+#pragma unroll
+        for (int u = 0; u < NG; ++u)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            typename T::vec4 o;
+            const f32x4_t v4 = silu4(add4(a0[u][nt], bb0[nt]));      // (silu2 pins the fp32 product: the 16-bit rounding is a second one, as everywhere)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (elem)v4[q];
+            w[u][nt] = __builtin_bit_cast(u32x2, o);
+            if constexpr (EDGE) {                                    // outside the first layer's map: the second layer's zero padding
+              w[u][nt][0] = inmap[u] ? w[u][nt][0] : 0u;
+              w[u][nt][1] = inmap[u] ? w[u][nt][1] : 0u;
+            }
+          }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+          *(u32x2*)(smem + wr[u]) = w[u][0];
+          *(u32x2*)(smem + (wr[u] ^ 32u)) = w[u][1];
         }
       };
       static_assert(GROUPS == 37, "nine groups per wave and one more for wave 0");
-#pragma unroll 3
-      for (int j = 0; j < 9; ++j) do_group(4 * j + wave);
-      if (wave == 0) do_group(36);
+      // (entries of the halo's padding rows -- never read by the second layer -- keep whatever finite value their lanes compute)
+      const bool edge = ty == 0 || tx == 0 || hy0 + HH > g.H || hx0 + HWD > g.Wd;
+      if (edge) {
+#pragma unroll 1
+        for (int j = 0; j < 9; j += 3) do_groups(std::integral_constant<int, 3>{}, std::true_type{}, 4 * j + wave);
+        if (wave == 0) do_groups(std::integral_constant<int, 1>{}, std::true_type{}, 36);
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < 9; j += 3) do_groups(std::integral_constant<int, 3>{}, std::false_type{}, 4 * j + wave);
+        if (wave == 0) do_groups(std::integral_constant<int, 1>{}, std::false_type{}, 36);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // the halo is complete
@@ -3391,7 +3442,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pair_kernel(const StemPairAr
 
 template <class T>
 int launch_conv_stem_pair(const StemPairArgs& g, hipStream_t s) {
-  constexpr int LDS = 592 * 64 + 2 * 11 * 1024 + 96 * 4;
+  constexpr int LDS = 592 * 64 + 2 * 11 * 1024 + 96 * 4 + 592 * 8;
   auto kern = conv_stem_pair_kernel<T>;
   static HmLdsOnce lds_once;
   if (const int rc = lds_once.ensure((const void*)kern, LDS, "hm_conv2d_stem_pair: cannot raise the dynamic LDS limit")) return rc;
@@ -4022,6 +4073,18 @@ int launch_conv(const KArgs& g0, int epilogue, void* ws, size_t ws_bytes, hipStr
         default: return launch_conv_tile<T, HM_EPI_RELU>(g, t_ser, s, deep);
       }
     }
+  }
+  // 1x1, stride 1, SiLU, Cout % 256 == 0 over at least a round and a half of whole 256 x 256 tiles (a batched pass: the 512 -> 512 /
+  // 1024 -> 1024 / 512 -> 256 transitions of the 48 x 80 and 24 x 40 maps): a plain GEMM -- the PERSISTENT kernel of the ViT
+  // (gemm_px_kernel, SiLU in its lane-swap epilogue).  As one-tile workgroups these layers spend as long outside their 8-16
+  // K-steps (launch, ring fill, epilogue; one workgroup per CU) as inside.  Same K order and epilogue arithmetic: same bytes
+  // (test_conv_1x1_persistent_kernel_equals_the_tile_kernel).  HM_OPT_CONV_TILE = 16 forces it where it applies, any other forced tile
+  // excludes it.
+  if (epilogue == HM_EPI_SILU && ks <= 1 && kgr == 1 && g.ksz == 1 && g.stride == 1 && g.K == (1 << g.cin_log2) && px_ok(g)) {   // (kgr: the persistent kernel has the one-group summation order only)
+    const int forced = hm_option(HM_OPT_CONV_TILE), tiles = (g.M >> 8) * (g.N >> 8);
+    int cus = hm_device_cu_count();
+    if (cus <= 0) cus = 256;
+    if (forced == CT_COUNT + 1 || (forced == 0 && 2 * tiles >= 3 * cus && g.K >= 256)) return launch_px<T, HM_EPI_SILU>(g, s);
   }
   const int t = pick_conv_tile(g, ks, kgr);
   const bool deep = conv_deep_ring(g, t, conv_tiles(g, t) * (ks > 1 ? ks : 1), g.K / 64 / (ks > 1 ? ks : 1));

@@ -96,7 +96,7 @@ enum {
   HM_OPT_TOME_NO_SPLITK = 4,        /* 1: token-merging forward never splits proj / fc2 over K (tests compare the routes) */
   HM_OPT_TOME_SCALAR_ATTENTION = 5, /* 1: hm_tome_attention takes the fp32 lane-per-key kernel                           */
   HM_OPT_RESID_IN_EPILOGUE = 6,     /* 1: the fp32-residual GEMM fetches its residual rows in the epilogue (round-2 form) */
-  HM_OPT_CONV_TILE = 7,             /* tuning: force convolution tile (1..9 = 128x128, 128x64, 128x32, 256x128, 256x256, 256x64, then the deep-ring 128x32, 128x64, 128x128); 0 = per-layer choice */
+  HM_OPT_CONV_TILE = 7,             /* tuning: force convolution tile (1..9 = 128x128, 128x64, 128x32, 256x128, 256x256, 256x64, then the deep-ring 128x32, 128x64, 128x128; 10..15 = the two-K-group tiles; 16 = the persistent 256x256 GEMM kernel for the 1x1 layers it applies to); 0 = per-layer choice */
   HM_OPT_CONV_SPLITK = 8,           /* tuning: 1 = never split a convolution over K, n > 1 = ask for n ranges where splitting applies; 0 = automatic */
   HM_OPT_PX_LDS_EPILOGUE = 9,       /* persistent GEMM epilogue: 0 = per epilogue (GELU: lane swaps, store: through LDS), 1 = always LDS, 2 = always lane swaps */
   HM_OPT_CONV_DIRECT = 10,          /* direct kernels (3x3: 3(8) -> 32 stem, 64 -> 64 stride 1, 32 -> 64 stride 2; 1x1 with K, Cout in {128, 256}): 0 = all, each from its own tile count up, 1 = none (implicit GEMM everywhere), 2 = stem only, 3 = all at any size */

@@ -273,6 +273,31 @@ def test_conv_3x3_stride2_32_to_64_kernel_equals_the_implicit_gemm(n, H, W, Ci, 
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Ci,Co,n,H,W", [(512, 512, 2, 48, 80), (1024, 256, 1, 48, 64), (256, 512, 3, 16, 64), (256, 1024, 48, 24, 40)])
+def test_conv_1x1_persistent_kernel_equals_the_tile_kernel(Ci, Co, n, H, W, dt):
+    """Round 4: 1x1 / stride 1 / SiLU layers with Cout % 256 == 0 and whole 256-row tiles are plain GEMMs and, from a round
+    and a half of 256 x 256 tiles up, run on the ViT's persistent kernel (gemm_px_kernel with a SiLU epilogue).  Same K order,
+    same epilogue arithmetic: the bytes equal the one-tile 256 x 256 kernel's and the 128 x 128 kernel's (HM_OPT_CONV_TILE = 16
+    forces the persistent kernel at any size, 5 / 1 the tiles), input and output as channel slices of wider buffers; the last
+    shape is one the default rule sends there by itself.  (Layers whose per-image rule sums two K groups -- at most 1024 pixels
+    per image and K >= 512 -- keep their tile kernels: the persistent kernel has the one-group order only.)"""
+    x = synth.uniform("px", (n, Ci, H, W), 1.0, seed=Ci + W).to(dt).float()
+    w = synth.uniform("pw", (Co, Ci, 1, 1), (3.0 / Ci) ** 0.5, seed=Co).to(dt).float()
+    b = synth.uniform("pb", (Co,), 0.3, seed=5)
+    with L.option(L.HM_OPT_CONV_TILE, 16):
+        pers = _conv_gpu(x, w, b, 1, 1, act=True, dt=dt, ld_extra=64, y_extra=192)
+    for tile in (5, 1):
+        with L.option(L.HM_OPT_CONV_TILE, tile):
+            assert torch.equal(pers, _conv_gpu(x, w, b, 1, 1, act=True, dt=dt, ld_extra=64, y_extra=192)), tile
+    if n == 48:
+        assert torch.equal(pers, _conv_gpu(x, w, b, 1, 1, act=True, dt=dt, ld_extra=64, y_extra=192))          # the default rule
+    if n * H * W <= 4096:
+        ref = F.silu(F.conv2d(x.double(), w.double(), b.double())).float()
+        ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        np.testing.assert_allclose(pers.numpy(), ref.numpy(), atol=2e-3, rtol=2 * ulp)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("Ci,Co,n,H,W", [(256, 256, 1, 8, 8), (256, 128, 2, 16, 12), (128, 128, 3, 8, 24), (128, 256, 1, 16, 20), (256, 256, 16, 96, 160),
                                           (128, 128, 16, 96, 160)])
 def test_conv_1x1_weights_in_registers_kernel_equals_the_implicit_gemm(Ci, Co, n, H, W, dt):
