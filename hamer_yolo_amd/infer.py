@@ -481,7 +481,7 @@ def shard_paths(paths: List[str], rank: int = 0, world: int = 1) -> List[str]:
 def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_step: int = FRAMES_PER_STEP, in_flight: int = 2,
                         decode_threads: Optional[int] = None, depth_model=None, hands_per_forward: int = HANDS_PER_FORWARD,
                         det_frames: Optional[int] = None, rank: int = 0, world: int = 1, stats: Optional[Dict] = None,
-                        overlap_detector: bool = True):
+                        overlap_detector: bool = True, balance_tail: bool = True, det_ramp=None):
     """Yields ``(path, detection_list, hands)`` per image that has detections, in path order; ``hands`` is a dict of host
     numpy arrays for that image's hands in detection order: betas (n,10), global_orient (n,1,3,3), hand_pose (n,15,3,3),
     cam_t (n,3), do_flip (n,), plus the axis-angle forms pose_global (n,3) and pose_hand (n,45).
@@ -491,6 +491,8 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
     ``rank`` / ``world``: this process handles ``shard_paths(image_paths, rank, world)`` only.
     ``stats`` (optional dict) receives ``images`` (files of this rank), ``frames`` (files with a result), ``hands`` (hands that
     went through HaMeR), ``det_passes`` and ``forwards``.
+    ``balance_tail=False``: the folder's last hands go out as forwards of ``hands_per_forward`` and one remainder (up to 1.25 x)
+    instead of equal parts on all streams.
     ``overlap_detector=False`` puts the detector passes on the first HaMeR stream (with ``in_flight=1``: a strictly serial
     GPU timeline, what bench.py's per-launch profile pass wants)."""
     from collections import deque
@@ -502,6 +504,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
     H = max(1, int(hands_per_forward))
     first_pass = max(1, int(frames_per_step))
     big_pass = max(first_pass, int(det_frames) if det_frames else (DET_FRAMES if first_pass >= FRAMES_PER_STEP else first_pass))
+    ramp = [max(1, int(x)) for x in det_ramp] if det_ramp else [first_pass]      # sizes of the first detector passes (tuning: e.g. (8, 8))
     n_streams = max(1, in_flight)
     if on_gpu:
         streams = _driver_streams(dev, n_streams + 1)         # [0 .. in_flight) HaMeR batches, the last one the detector's
@@ -733,12 +736,13 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             return items
 
         passes = 0
+        tail_plan = None                                              # sizes of the last forwards, fixed once the folder's last hands are queued
         while True:
             frames_left = carry is not None or taken < len(image_paths)
             # 1. keep the detector ahead of HaMeR: a pass in flight whenever fewer than ~3 batches of hands are queued or expected
             expected = len(queue) + sum(len(j["items"]) for j in det_jobs) * hands_per_frame
             if frames_left and len(det_jobs) < 2 and expected < 3 * H:
-                items = next_items(first_pass if passes == 0 else big_pass)
+                items = next_items(ramp[passes] if passes < len(ramp) else big_pass)
                 if items:
                     mark(f"det_items_ready {len(items)}")
                     passes += 1
@@ -753,8 +757,24 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             # 2. full batches as long as the queue holds them; at the end of the folder the remainder (a last batch of up to
             #    H + H/4 hands rather than a full one and a sliver)
             draining = not frames_left and not det_jobs
+            if draining and queue and tail_plan is None:
+                # the end of the folder: what is queued now is all there will be.  Forwards of H hands until the rest fits two
+                # forwards of at most 1.5 H, and that rest in EQUAL parts, one per stream -- the streams then finish together (a
+                # last forward running alone costs 8 % more per hand than two in flight, and a full one followed by a sliver
+                # twice that; forwards of 40 .. 96 hands cost within 6 % of the tuned 64 per hand)
+                rest, tail_plan = len(queue), []
+                while balance_tail and rest > n_streams * (H + H // 2):
+                    tail_plan.append(H); rest -= H
+                if balance_tail and n_streams > 1 and rest > H // 2:
+                    parts = n_streams if rest <= n_streams * (H + H // 2) else 2 * n_streams
+                    tail_plan += [rest // parts + (1 if i < rest % parts else 0) for i in range(parts)]
+                else:
+                    while rest > H + H // 4:
+                        tail_plan.append(H); rest -= H
+                    tail_plan.append(rest)
             while len(batches) < 2 * n_streams and (len(queue) >= H or (draining and queue)):
-                take = len(queue) if (draining and len(queue) <= H + H // 4) else H
+                take = tail_plan.pop(0) if (draining and tail_plan) else H
+                take = min(take, len(queue))
                 hands = [queue.popleft() for _ in range(take)]
                 stream = hstreams[st["forwards"] % n_streams]
                 try:

@@ -127,13 +127,25 @@ def test_results_are_per_file_whatever_the_pass_and_batch_sizes(folder):
     for kw in (dict(hands_per_forward=5, frames_per_step=3, det_frames=7), dict(hands_per_forward=1, frames_per_step=1),
                dict(hands_per_forward=16, frames_per_step=2, det_frames=2, in_flight=3, decode_threads=2),
                dict(hands_per_forward=7, frames_per_step=16, in_flight=1)):
-        got, st2, det2, ham2 = _collect(folder, **kw)
+        got, st2, det2, ham2 = _collect(folder, balance_tail=False, **kw)
         _same(base, got)
         H = kw["hands_per_forward"]
         # every forward but the last is EXACTLY hands_per_forward hands, across frame and pass boundaries; the last takes the
         # remainder (up to H + H/4 rather than a full batch and a sliver)
         assert all(b == H for b in ham2.batch_sizes[:-1]) and 0 < ham2.batch_sizes[-1] <= H + H // 4, ham2.batch_sizes
         assert sum(ham2.batch_sizes) == st2["hands"] == st["hands"]
+        # the default: the same forwards of exactly H hands, then -- once the folder's last hands are queued -- the rest in
+        # EQUAL parts (within one hand) of at most 1.5 H, one or two per stream, so that the streams finish together
+        got3, st3, det3, ham3 = _collect(folder, **kw)
+        _same(base, got3)
+        sizes, n_str = ham3.batch_sizes, kw.get("in_flight", 2)
+        k = 0
+        while k < len(sizes) and sizes[k] == H:
+            k += 1
+        tail = sizes[k:]
+        assert sum(sizes) == st3["hands"] == st["hands"] and len(tail) <= 2 * n_str, sizes
+        assert not tail or (max(tail) - min(tail) <= 1 and 0 < max(tail) <= H + H // 2) or (n_str == 1 and len(tail) == 1 and tail[0] <= H + H // 4), sizes
+        assert det3.pass_sizes == det2.pass_sizes
         # a detector pass holds frames of ONE size: first pass <= frames_per_step, later ones <= det_frames
         assert det2.pass_sizes[0] <= kw["frames_per_step"] and max(det2.pass_sizes) <= max(kw.get("det_frames", kw["frames_per_step"]), kw["frames_per_step"])
         assert sum(det2.pass_sizes) == 22
