@@ -1986,7 +1986,9 @@ int launch_px(const KArgs& g, hipStream_t s) {
   const bool staged = form == 1 || (form == 0 && ((PIPE == 1 || PIPE == 2) || (EPI != HM_EPI_GELU && EPI != HM_EPI_SILU)));
   if (PIPE == 4 && !g.ln_stats) return hm_set_error(HM_ERR_ARG, "hm_gemm: variant 35 (stamps) needs a device buffer of 6 x 8 bytes per workgroup in ln_stats");   // (pipelined kernel: the lane-swap GELU form does not fit the register file)
 #ifdef HM_ABLATIONS
-  auto kern = PIPE == 9 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, false, 2> : gemm_px_kernel<T, EPI, true, false, false, true, true, false, 2>)
+  void (*kern)(const KArgs) = nullptr;
+  if constexpr (PIPE == 0) kern = staged ? gemm_px_kernel<T, EPI, false> : gemm_px_kernel<T, EPI, true>;     // (the only form a SiLU epilogue exists in)
+  else kern = PIPE == 9 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, false, 2> : gemm_px_kernel<T, EPI, true, false, false, true, true, false, 2>)
             : PIPE == 8 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, false, 1> : gemm_px_kernel<T, EPI, true, false, false, true, true, false, 1>)
             : PIPE == 7 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, true, true> : gemm_px_kernel<T, EPI, true, false, false, true, true, true>)
             : PIPE == 6 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, false> : gemm_px_kernel<T, EPI, true, false, false, true, false>)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libhamer_hip.so")
 HM_DTYPE_BF16, HM_DTYPE_F16, HM_OUT_F32 = 0, 1, 2
 HM_EPI_STORE, HM_EPI_GELU, HM_EPI_RESID_F32, HM_EPI_F32, HM_EPI_SILU = 0, 1, 2, 3, 4
 HM_EPI_RESID_LN, HM_EPI_LN_STORE, HM_EPI_LN_GELU, HM_EPI_GELU_MX8 = 5, 6, 7, 8
-HM_VERSION = 400      # include/hamer_hip.h: load() refuses a library built from another header
+HM_VERSION = 401      # include/hamer_hip.h: load() refuses a library built from another header
 # the HM_OPT_* keys of include/hamer_hip.h, in enum order: load() checks the count against the library's hm_option_count(), and
 # tests/test_host_logic.py parses the header's enum and compares names and values with this table
 OPTION_NAMES = ("HM_OPT_PX_GRID", "HM_OPT_FP8P_GRID", "HM_OPT_FP8_ONE_TILE", "HM_OPT_FP8P_RESID", "HM_OPT_TOME_NO_SPLITK",

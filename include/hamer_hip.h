@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HM_VERSION 400   /* round 4: hm_option_count, hm_gemm_px_grid (302 = round 3: hm_set_option, hm_hamer_weights.tome_r) -- lib.load() checks it */
+#define HM_VERSION 401   /* 401: hm_conv2d_stem_pair, HM_OP_CONV_PAIR, HM_OPT_CONV_STEM_PAIR; 400 = round 4: hm_option_count, hm_gemm_px_grid (302 = round 3: hm_set_option, hm_hamer_weights.tome_r) -- lib.load() checks it */
 
 enum { HM_DTYPE_BF16 = 0, HM_DTYPE_F16 = 1 };
 
