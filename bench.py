@@ -351,8 +351,9 @@ def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value, ctxs):
             o["cpu_baseline_detector"] = cpu_baseline_detector(E2E_WEIGHTS_4_HANDS)
         return o
 
-    for key, name, fn in (("shard", "configs[3] shard1024, N=1", side_shard), ("fp8", "configs[4] fp8 ViT-H, B=256", side_fp8),
-                          ("e2e", "configs[2] e2e 1080p, ~4 hands/frame", side_e2e)):
+    # (e2e first: behind the other two its 64-frame pass read 96.8 ms against 92.4 on its own, same box -- profiles/r04_bench_v9_*)
+    for key, name, fn in (("e2e", "configs[2] e2e 1080p, ~4 hands/frame", side_e2e), ("shard", "configs[3] shard1024, N=1", side_shard),
+                          ("fp8", "configs[4] fp8 ViT-H, B=256", side_fp8)):
         if key in only:
             out[name] = fn()
             torch.cuda.empty_cache()

@@ -448,6 +448,19 @@ def test_maxpool_and_upsample():
     y = torch.empty(1, 6, 10, 64, dtype=torch.float16, device=DEV)
     L.check(lib.hm_maxpool_nhwc(xd.data_ptr(), 64, y.data_ptr(), 64, 1, 12, 20, 64, 2, 2, 0, L.HM_DTYPE_F16, L.current_stream()))
     assert torch.equal(y.cpu().permute(0, 3, 1, 2), F.max_pool2d(x.float(), 2, 2).half())
+    # MP (k 2, stride 2): the two-outputs-per-thread kernel (even maps, W % 4 == 0) and the generic one, several frames, input and
+    # output as channel slices of wider buffers, both dtypes
+    for n, Cc, Hh, Ww, dt in ((3, 128, 16, 24, torch.float16), (2, 64, 10, 14, torch.float16), (2, 256, 8, 12, torch.bfloat16), (1, 64, 7, 9, torch.bfloat16)):
+        xs = synth.uniform("mp", (n, Cc, Hh, Ww), 2.0, seed=Hh).to(dt)
+        xb = torch.zeros(n, Hh, Ww, Cc + 64, dtype=dt)
+        xb[..., 32:32 + Cc] = xs.permute(0, 2, 3, 1)
+        xbd = xb.to(DEV)
+        yb = torch.full((n, Hh // 2, Ww // 2, Cc + 32), 3.0, dtype=dt, device=DEV)
+        L.check(lib.hm_maxpool_nhwc(xbd.data_ptr() + 64, Cc + 64, yb.data_ptr() + 32, Cc + 32, n, Hh, Ww, Cc, 2, 2, 0,
+                                    L.HM_DTYPE_BF16 if dt == torch.bfloat16 else L.HM_DTYPE_F16, L.current_stream()))
+        got = yb.cpu()
+        assert torch.equal(got[..., 16:16 + Cc].permute(0, 3, 1, 2).float(), F.max_pool2d(xs.float(), 2, 2)), (n, Cc, Hh, Ww)
+        assert (got[..., :16] == 3.0).all() and (got[..., 16 + Cc:] == 3.0).all()
     # SPP cascade: 5, 9 = 5o5, 13 = 5o5o5 written into channel slices of one buffer
     cat = torch.zeros(1, 12, 20, 256, dtype=torch.float16, device=DEV)
     cat[..., :64] = xd
