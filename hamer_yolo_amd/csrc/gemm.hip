@@ -1313,6 +1313,7 @@ int launch_d2(const KArgs& g, hipStream_t s) {
 template <class T, int EPI, bool DIRECT = true, bool DMAW = false, bool STAMP = false, bool LEAN = true, bool XFIRST = true, bool R1EARLY = false, int TWEAK = 0>
 __global__ __launch_bounds__(512, 2) void gemm_px_kernel(const KArgs g) {
   static_assert(EPI == HM_EPI_STORE || EPI == HM_EPI_GELU || EPI == HM_EPI_SILU, "16-bit store epilogues only");
+  static_assert(!(DMAW && LEAN), "the loader-wave experiment was written against the round-3 copy issue");
   constexpr int WN = 2, MI = 4, NI = 8, ROWB = 128;
   constexpr int TILE_BYTES = 256 * ROWB;                               // 32 KB
   constexpr int XRING = 0, WRING = 3 * TILE_BYTES;
@@ -1994,7 +1995,7 @@ int launch_px(const KArgs& g, hipStream_t s) {
             : PIPE == 6 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, true, false> : gemm_px_kernel<T, EPI, true, false, false, true, false>)
             : PIPE == 5 ? (staged ? gemm_px_kernel<T, EPI, false, false, false, false> : gemm_px_kernel<T, EPI, true, false, false, false>)
             : PIPE == 4 ? (staged ? gemm_px_kernel<T, EPI, false, false, true> : gemm_px_kernel<T, EPI, true, false, true>)
-            : PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true> : gemm_px_kernel<T, EPI, true, true>)
+            : PIPE == 3 ? (staged ? gemm_px_kernel<T, EPI, false, true, false, false, false> : gemm_px_kernel<T, EPI, true, true, false, false, false>)   // (as measured: round 3's copy issue and read order)
             : PIPE == 2 ? (staged ? gemm_pp_kernel<T, EPI, false, true> : gemm_pp_kernel<T, EPI, true, true>)
             : PIPE ? (staged ? gemm_pp_kernel<T, EPI, false> : gemm_pp_kernel<T, EPI, true>)
                    : (staged ? gemm_px_kernel<T, EPI, false> : gemm_px_kernel<T, EPI, true>);
