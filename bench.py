@@ -256,7 +256,7 @@ def run_e2e(args, dev, dtype, yolo_weights="synthetic:2:-2.2:0", chunks_per_pass
                                               "infer.process_batch_manopara (the README entry point), detector boxes used as found"),
                                  "first_detector_pass_frames": F, "detector_pass_frames": getattr(args, "det_frames", 0) or infer.DET_FRAMES, "hands_per_forward": infer.HANDS_PER_FORWARD,
                                  "batches_in_flight": 2, "detector_weights": yolo_weights, "frames_per_rank_and_pass": per_rank,
-                                 "parallelism": f"frames round-robin x{world}", "forwards_per_pass_rank0": st.get("forwards"),
+                                 "parallelism": f"frames round-robin x{world}", "forwards_per_pass_rank0": st.get("forwards"), "forward_sizes_rank0": st.get("forward_sizes"), "detector_pass_sizes_rank0": st.get("det_pass_sizes"),
                                  "detector_passes_per_pass_rank0": st.get("det_passes")},
                       "gflop_per_frame": round(61.9 + hands / n_frames * 251.03, 1),
                       **({"roofline": roof} if roof else {}), **({"long_pass": long_pass} if long_pass else {})})
@@ -342,7 +342,7 @@ def side_configs(args, dev, cfg, sd, mano_cpu, eng, contract_value, ctxs):
         o["vs_contract_line"] = round(r["value"] / contract_value, 4)
         o["detector_weights"] = E2E_WEIGHTS_4_HANDS
         o["pipeline"] = {k: r["config"][k] for k in ("first_detector_pass_frames", "detector_pass_frames", "hands_per_forward",
-                                                     "forwards_per_pass_rank0", "detector_passes_per_pass_rank0")}
+                                                     "forwards_per_pass_rank0", "detector_passes_per_pass_rank0", "forward_sizes_rank0", "detector_pass_sizes_rank0")}
         # long_pass: the same driver and models over a folder three times as long -- a 64-frame pass cannot hide the fill of
         # the pipeline (decode + upload + detector pass of the first frames with nothing to overlap) and its drain
         o["long_pass"] = r["long_pass"]

@@ -490,7 +490,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
     per-hand try/except drops them.
     ``rank`` / ``world``: this process handles ``shard_paths(image_paths, rank, world)`` only.
     ``stats`` (optional dict) receives ``images`` (files of this rank), ``frames`` (files with a result), ``hands`` (hands that
-    went through HaMeR), ``det_passes`` and ``forwards``.
+    went through HaMeR), ``det_passes`` and ``forwards`` (and their sizes, ``det_pass_sizes`` / ``forward_sizes``, in launch order).
     ``balance_tail=False``: the folder's last hands go out as forwards of ``hands_per_forward`` and one remainder (up to 1.25 x)
     instead of equal parts on all streams.
     ``overlap_detector=False`` puts the detector passes on the first HaMeR stream (with ``in_flight=1``: a strictly serial
@@ -514,7 +514,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
         hstreams, dstream = [_Cpu.Stream() for _ in range(n_streams)], _Cpu.Stream()
         new_event, stream_ctx = _Cpu.Event, _Cpu.ctx
     st = stats if stats is not None else {}
-    st.update(images=len(image_paths), frames=0, hands=0, det_passes=0, forwards=0)
+    st.update(images=len(image_paths), frames=0, hands=0, det_passes=0, forwards=0, forward_sizes=[], det_pass_sizes=[])
     import time as _time
     _t0 = _time.perf_counter()
     trace = st.setdefault("trace", []) if os.environ.get("HAMER_E2E_TRACE") == "1" else None      # (host timeline of a pass, ms: tuning runs)
@@ -588,6 +588,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             done = new_event()
             done.record(dstream)
         st["det_passes"] += 1
+        st["det_pass_sizes"].append(len(items))
         mark(f"det_enqueued {len(items)}")
         return {"items": items, "frames": frames, "token": token, "done": done}
 
@@ -647,6 +648,7 @@ def iter_folder_results(image_paths, hamer, detector, k_real=None, frames_per_st
             done = new_event()
             done.record(stream)          # (its own event: a stream synchronise would also wait for the NEXT batch queued on that stream)
         st["forwards"] += 1
+        st["forward_sizes"].append(len(hands))
         mark(f"batch_enqueued {len(hands)}")
         return {"done": done, "hands": [(fi, j) for fi, j, _ in hands], "dev": dev_res, "frames": frames}   # (frames: alive until finish)
 
