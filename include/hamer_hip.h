@@ -99,7 +99,7 @@ enum {
   HM_OPT_CONV_TILE = 7,             /* tuning: force convolution tile (1..9 = 128x128, 128x64, 128x32, 256x128, 256x256, 256x64, then the deep-ring 128x32, 128x64, 128x128; 10..15 = the two-K-group tiles; 16 = the persistent 256x256 GEMM kernel for the 1x1 layers it applies to); 0 = per-layer choice */
   HM_OPT_CONV_SPLITK = 8,           /* tuning: 1 = never split a convolution over K, n > 1 = ask for n ranges where splitting applies; 0 = automatic */
   HM_OPT_PX_LDS_EPILOGUE = 9,       /* persistent GEMM epilogue: 0 = per epilogue (GELU: lane swaps, store: through LDS), 1 = always LDS, 2 = always lane swaps */
-  HM_OPT_CONV_DIRECT = 10,          /* direct kernels (3x3: 3(8) -> 32 stem, 64 -> 64 stride 1, 32 -> 64 stride 2; 1x1 with K, Cout in {128, 256}): 0 = all, each from its own tile count up, 1 = none (implicit GEMM everywhere), 2 = stem only, 3 = all at any size */
+  HM_OPT_CONV_DIRECT = 10,          /* direct kernels (3x3: 3(8) -> 32 stem, 64 -> 64 stride 1, 32 -> 64 stride 2; 1x1 with K, Cout in {128, 256}): 0 = all, each from its own tile count up, 1 = none (implicit GEMM everywhere), 2 = stem only, 3 = all at any size (experiments library only: 4 / 5 = the two stem layers without their activation / without their stores, WRONG results, bound diagnosis) */
   HM_OPT_GEMM_TILE_RULE = 11,       /* tuning: 1 = round 2's GEMM tile rule (256 x 256 only from 85 % full rounds), 0 = the rate model */
   HM_OPT_CONV_KGROUPS = 12,         /* tuning: 1 = no K groups inside a convolution workgroup (small maps), 0 = automatic */
   HM_OPT_CONV_GENERAL_LOADER = 13,  /* tuning / tests: 1 = the implicit-GEMM convolution takes its general loader (per-lane tap arithmetic every K-step) even where the lean one applies (Cin % 64 == 0); 0 = automatic.  Same bytes either way */

@@ -9,7 +9,7 @@ timeout -k 10 600 python3 -m pytest tests/test_gpu_yolo.py -x -q -m gpu -k "pers
 tail -1 $O/t1.log
 timeout -k 10 300 python3 tools/prof_yolo.py 48 > $O/yolo48_auto.log 2>&1 || { tail -20 $O/yolo48_auto.log; exit 1; }
 CONV_TILE=16 timeout -k 10 300 python3 tools/prof_yolo.py 48 > $O/yolo48_px_forced.log 2>&1 || { tail -20 $O/yolo48_px_forced.log; exit 1; }
-HM_NO_PX_CONV=1 CONV_TILE=0 timeout -k 10 300 python3 tools/prof_yolo.py 16 > $O/yolo16_auto.log 2>&1 || { tail -20 $O/yolo16_auto.log; exit 1; }
+CONV_TILE=0 timeout -k 10 300 python3 tools/prof_yolo.py 16 > $O/yolo16_auto.log 2>&1 || { tail -20 $O/yolo16_auto.log; exit 1; }
 python3 - <<'PY'
 import re
 def rows(f):
