@@ -192,3 +192,52 @@ def test_detector_boxes_against_the_fp32_cpu_detector():
     assert n_match >= 0.6 * min(n_gpu, n_ref) and n_match >= 8          # most boxes have a partner in the fp32 list
     assert labels_ok == n_match                                           # and the same label
     assert max(d_rel) <= 0.05                                             # corners within 5 % of the box size
+
+
+def test_frame_ring_reuse_under_the_real_gpu_pipeline(tmp_path):
+    """ADVICE r3 (page-locked frame ring): 48 distinct 1080p .bmp files through the folder driver with pass sizes that make
+    every page-locked slot carry THREE files in turn (ring of 16 slots: frames_per_step = 2, det_frames = 4), uploads,
+    detector passes and HaMeR batches in flight on three streams.  A slot rewritten under a pending copy, or a frame read
+    before its upload had landed, would change some file's boxes or hands: the saved records must be BIT-EQUAL between two
+    such runs and equal the run with the default (large, never reused) ring -- the detector's boxes exactly (batch-invariant
+    kernels) and the hands within the HaMeR kernels' batch-composition noise (4e-5, test_batch64_is_batch_invariant)."""
+    from PIL import Image
+    from hamer_yolo_amd import infer
+    ind = tmp_path / "rgb"
+    ind.mkdir()
+    n = 48
+    for i in range(n):
+        fr = synth.frame_u8(1080, 1920, seed=i % 6).numpy().copy()
+        fr[8:40, 8:8 + 4 * (i + 1)] = 255 - 3 * i                       # every file distinct: a stale slot cannot go unnoticed
+        Image.fromarray(fr[:, :, ::-1]).save(str(ind / f"f{i:04d}.bmp"))
+    hi, det = hamer_inference(_HCfg), Detector(_YCfg)
+
+    def run(tag, **kw):
+        out = tmp_path / tag
+        st = process_batch_manopara(str(ind), str(out), None, hamer=hi, detector=det, **kw)
+        recs = {}
+        for f in sorted(os.listdir(out)):
+            recs[f] = np.load(str(out / f), allow_pickle=True)
+        return st, recs
+
+    st_a, a = run("a", frames_per_step=2, det_frames=4, hands_per_forward=16)
+    st_b, b = run("b", frames_per_step=2, det_frames=4, hands_per_forward=16)
+    st_c, c = run("c")
+    assert st_a["det_pass_sizes"][0] == 2 and max(st_a["det_pass_sizes"]) == 4 and len(st_a["det_pass_sizes"]) >= 12
+    assert st_a["hands"] == st_b["hands"] == st_c["hands"] > 200 and sorted(a) == sorted(b) == sorted(c) and len(a) >= 32
+
+    def rows(rec):                                       # {'left': record or None, 'right': record or None} (infer.py:1296-1304)
+        r = rec.item()
+        return [r[k] for k in ("left", "right")]
+    worst = 0.0
+    for f in a:
+        ra, rb, rc = rows(a[f]), rows(b[f]), rows(c[f])
+        for x, y, z in zip(ra, rb, rc):
+            assert (x is None) == (y is None) == (z is None), f
+            if x is None:
+                continue
+            for k in ("betas", "theta", "cam_t"):
+                assert np.array_equal(np.asarray(x[k]), np.asarray(y[k])), (f, k)          # same schedule: same bytes
+                worst = max(worst, float(np.abs(np.asarray(x[k], np.float64) - np.asarray(z[k], np.float64)).max() / max(1.0, float(np.abs(np.asarray(z[k])).max()))))
+            assert x["is_right"] == z["is_right"], f
+    assert worst < 2e-4, worst
